@@ -1,0 +1,265 @@
+/*
+ * rtamd.h -- C ABI of the MI355X (gfx950) render hot path.
+ *
+ * This is the boundary a Rust `-sys` crate of the reference renderer would bind: the host keeps its
+ * Scene / Integrator / render entry points and its own BVH builder, flattens its scene into the
+ * plain arrays below, and calls these functions instead of walking the scene on the CPU.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a non-zero RTAMD_E_* code on failure; the message is
+ *     available from rtamd_last_error() (context-owned string, valid until the next call);
+ *   - nothing aborts or throws across the boundary;
+ *   - all arrays passed to rtamd_upload_scene() stay owned by the caller and are copied;
+ *   - calls are blocking unless they take a stream; a context is bound to one GPU and is not
+ *     re-entrant (use one host thread per context);
+ *   - all floating point data is IEEE binary32, indices are uint32.
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTAMD_MISS 0xFFFFFFFFu
+
+enum rtamd_error {
+    RTAMD_OK = 0,
+    RTAMD_E_INVALID = 1,   /* bad argument / inconsistent scene description */
+    RTAMD_E_DEVICE = 2,    /* HIP runtime error */
+    RTAMD_E_NOSCENE = 3,   /* trace/render before a scene was uploaded */
+    RTAMD_E_UNSUPPORTED = 4
+};
+
+typedef struct rtamd_context rtamd_context;
+
+/* ---- scene description ------------------------------------------------------------------------ */
+
+/* One node of the reference's flat pre-order tree, `(AABB, skip, first)`:
+ * replaces the element type of AABBTree::nodes, src/geom/bvh.rs:5-8.  The array includes the
+ * trailing sentinel node `(empty, m, n)` pushed at src/geom/bvh.rs:164-165. */
+typedef struct rtamd_bvh_node {
+    float min[3];
+    float max[3];
+    uint32_t skip;
+    uint32_t first;
+} rtamd_bvh_node;
+
+/* Mesh = AABBTree<MeshTriangle> over a shared [vertices || normals] array:
+ * replaces struct Mesh / MeshTriangle, src/geom/mesh.rs:11-52.  `tri_indices` holds the three
+ * vertex indices of every triangle in TREE (leaf) order, i.e. AABBTree::objs after construction. */
+typedef struct rtamd_mesh {
+    const rtamd_bvh_node* nodes;
+    uint32_t n_nodes;
+    const uint32_t* tri_indices;
+    uint32_t n_tris;
+    const float* vertices; /* 3 floats per vertex */
+    const float* normals;  /* 3 floats per vertex */
+    uint32_t n_verts;
+} rtamd_mesh;
+
+/* Cuboid{center, extent, inv_extent}: replaces struct Cuboid, src/geom/cuboid.rs:61-79. */
+typedef struct rtamd_cuboid {
+    float center[3];
+    float extent[3];
+    float inv_extent[3];
+} rtamd_cuboid;
+
+/* Standalone triangle: replaces struct Triangle, src/geom/triangle.rs:5-16. */
+typedef struct rtamd_triangle {
+    float a[3], b[3], c[3];
+} rtamd_triangle;
+
+/* One ray-space wrapper, applied outermost first: replaces Translate / Scale / Rotate,
+ * src/geom/transform.rs:5-22.
+ *   TRANSLATE: v[0..2] = offset            (transform.rs:55-72)
+ *   SCALE:     v[0] = scale, v[1] = inv    (transform.rs:100-120)
+ *   ROTATE:    v[0..8] = row-major 3x3     (transform.rs:175-198) */
+enum rtamd_op_kind { RTAMD_OP_TRANSLATE = 0, RTAMD_OP_SCALE = 1, RTAMD_OP_ROTATE = 2 };
+typedef struct rtamd_xform_op {
+    uint32_t kind;
+    float v[9];
+} rtamd_xform_op;
+
+/* Geometry primitive kinds an object can wrap. */
+enum rtamd_geom_kind {
+    RTAMD_GEOM_MESH = 0,        /* geom_index -> meshes[]          (mesh.rs) */
+    RTAMD_GEOM_UNIT_SPHERE = 1, /* geom_index ignored              (sphere.rs:35-74); Sphere = ops {TRANSLATE, SCALE} */
+    RTAMD_GEOM_CUBOID = 2,      /* geom_index -> cuboids[]         (cuboid.rs:81-105) */
+    RTAMD_GEOM_UNIT_CUBOID = 3, /* geom_index ignored              (cuboid.rs:18-59) */
+    RTAMD_GEOM_TRIANGLE = 4     /* geom_index -> triangles[]       (triangle.rs:40-69) */
+};
+
+/* Object = geometry + material: replaces ObjectImpl / Object, src/geom/aggregate.rs:98-148.
+ * ops[op_first .. op_first+op_count) are the wrappers between the object and its primitive. */
+typedef struct rtamd_object {
+    uint32_t geom_kind;
+    uint32_t geom_index;
+    uint32_t material;
+    uint32_t op_first;
+    uint32_t op_count;
+} rtamd_object;
+
+/* AABBTree<Object> (src/geom/bvh.rs:173): leaves are objects[first_object + k], k in tree order. */
+typedef struct rtamd_object_tree {
+    const rtamd_bvh_node* nodes;
+    uint32_t n_nodes;
+    uint32_t first_object;
+    uint32_t n_objects;
+} rtamd_object_tree;
+
+/* Scene root = GeometryList in order: replaces GeometryList, src/geom/aggregate.rs:23-45. */
+enum rtamd_root_kind { RTAMD_ROOT_OBJECT = 0, RTAMD_ROOT_OBJECT_TREE = 1 };
+typedef struct rtamd_root_item {
+    uint32_t kind;
+    uint32_t index; /* objects[] or trees[] */
+} rtamd_root_item;
+
+/* Materials: replaces the Material impls of src/material.rs:17-141 (constant-colour textures).
+ *   NULL: green diffuse; METAL; GLOSSY(p0 = exponent, p1 = mirror fraction, color);
+ *   TRANSPARENT(p0 = index of refraction); LAMBERT(color). */
+enum rtamd_material_kind { RTAMD_MAT_NULL = 0, RTAMD_MAT_METAL = 1, RTAMD_MAT_GLOSSY = 2, RTAMD_MAT_TRANSPARENT = 3, RTAMD_MAT_LAMBERT = 4 };
+typedef struct rtamd_material {
+    uint32_t kind;
+    float p0, p1;
+    float color[3];
+} rtamd_material;
+
+/* Lights: replaces the Light impls of src/light.rs:12-158.  emission = color * intensity.
+ *   AMBIENT; DIRECTION(vec = normalised direction, param = spread, <= 0: none);
+ *   AO(param = distance); POINT(vec = position, param = radius; not yet supported on the device). */
+enum rtamd_light_kind { RTAMD_LIGHT_AMBIENT = 0, RTAMD_LIGHT_POINT = 1, RTAMD_LIGHT_DIRECTION = 2, RTAMD_LIGHT_AO = 3 };
+typedef struct rtamd_light {
+    uint32_t kind;
+    float vec[3];
+    float param;
+    float emission[3];
+} rtamd_light;
+
+/* Whole scene: replaces struct Scene {root, skybox, lights}, src/scene.rs:8-13 (the camera travels
+ * with the render call).  skybox_rgb is the decoded RgbImage of texture::Image, src/texture.rs:49. */
+typedef struct rtamd_scene_desc {
+    const rtamd_mesh* meshes;           uint32_t n_meshes;
+    const rtamd_cuboid* cuboids;        uint32_t n_cuboids;
+    const rtamd_triangle* triangles;    uint32_t n_triangles;
+    const rtamd_xform_op* ops;          uint32_t n_ops;
+    const rtamd_object* objects;        uint32_t n_objects;
+    const rtamd_object_tree* trees;     uint32_t n_trees;
+    const rtamd_root_item* root;        uint32_t n_root;
+    const rtamd_material* materials;    uint32_t n_materials;
+    const rtamd_light* lights;          uint32_t n_lights;
+    const uint8_t* skybox_rgb;          uint32_t sky_w, sky_h;
+} rtamd_scene_desc;
+
+/* ---- ray batches ------------------------------------------------------------------------------- */
+
+/* Structure-of-arrays ray batch: replaces `&Ray` + `t_max` of Geometry::hit / is_hit,
+ * src/geom/mod.rs:30-33, one element per ray. */
+typedef struct rtamd_rays {
+    const float *ox, *oy, *oz; /* Ray::pos */
+    const float *dx, *dy, *dz; /* Ray::dir */
+    const float* tmax;
+} rtamd_rays;
+
+/* Closest-hit results: replaces Option<HitResult>, src/geom/mod.rs:20-26.
+ * obj = index into objects[] (RTAMD_MISS on a miss); prim = index of the primitive inside the
+ * object's innermost tree in tree order (0 for non-mesh objects); t is in the caller's space. */
+typedef struct rtamd_hits {
+    uint32_t* obj;
+    uint32_t* prim;
+    float *t, *u, *v;
+} rtamd_hits;
+
+/* ---- render ------------------------------------------------------------------------------------ */
+
+/* Camera: replaces struct Camera after its builder ran, src/scene.rs:25-32. */
+typedef struct rtamd_camera {
+    float pos[3], dir[3], horizontal[3], vertical[3];
+    uint32_t width, height;
+} rtamd_camera;
+
+/* Integrator parameters: replaces WhittedIntegrator, src/integrator.rs:12-19 (gamma is unused by
+ * the reference and absent here). */
+typedef struct rtamd_integrator {
+    int32_t max_depth, shadow_rays, scatter_rays, antialiasing;
+} rtamd_integrator;
+
+/* The pixels one call renders: the rectangle (x0,y0,w,h) of the camera image cut into tiles of
+ * tile_w x tile_h (row-major tile order, edge tiles clipped); this call owns tiles
+ * tile_first, tile_first + tile_stride, ...  With tile_stride = 1 the whole rectangle is rendered.
+ * Output layout: the owned tiles one after another, each a dense row-major tile_h x tile_w
+ * block (clipped tiles keep the full block size; pixels outside the rectangle are zero). */
+typedef struct rtamd_region {
+    uint32_t x0, y0, w, h;
+    uint32_t tile_w, tile_h;
+    uint32_t tile_first, tile_stride;
+} rtamd_region;
+
+typedef struct rtamd_stats {
+    uint64_t closest_rays; /* Scene::root.hit calls, src/integrator.rs:64 */
+    uint64_t any_rays;     /* Scene::root.is_hit calls, src/integrator.rs:124 */
+    uint64_t paths;        /* integrate_recur(depth 0) calls, src/integrator.rs:45 */
+    uint64_t launches;     /* kernels launched */
+    double device_ms;      /* HIP-event time of the whole render on the context's stream */
+    double trace_closest_ms, trace_any_ms, shade_ms; /* filled when profiling is enabled */
+} rtamd_stats;
+
+/* ---- entry points ------------------------------------------------------------------------------ */
+
+/* Create / destroy a context on one GPU.  No counterpart in the reference (it has no device). */
+int rtamd_create(int device_id, rtamd_context** out);
+void rtamd_destroy(rtamd_context* ctx);
+const char* rtamd_last_error(const rtamd_context* ctx);
+
+/* Copies the scene to the GPU in the device layout.  Replaces building `Scene` in
+ * src/main.rs:39-83 for the device side. */
+int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* scene);
+
+/* Batched Geometry::hit on the scene root (src/geom/mod.rs:30, caller src/integrator.rs:64).
+ * Host pointers; copies in and out. */
+int rtamd_trace_closest(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out);
+/* Batched Geometry::is_hit on the scene root (src/geom/mod.rs:31-33, caller src/integrator.rs:124).
+ * out[i] = 1 if occluded. */
+int rtamd_trace_any(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out);
+
+/* Same two calls on arrays that already live in this GPU's memory; asynchronous on `stream`
+ * (a hipStream_t, NULL = the context's own stream, in which case the call blocks until done). */
+int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream);
+int rtamd_trace_any_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out, void* stream);
+
+/* Number of floats-triples rtamd_render writes for a region (owned tiles x tile_w x tile_h). */
+size_t rtamd_region_pixels(const rtamd_region* region);
+
+/* render::parallel_render (src/render.rs:10-56) for the owned tiles of `region`:
+ * out_rgb receives rtamd_region_pixels() x 3 floats (linear, un-quantised, as
+ * WhittedIntegrator::calculate_pixel returns them, src/integrator.rs:33-56).
+ * rtamd_render writes host memory; rtamd_render_device writes this GPU's memory and blocks until
+ * the frame is complete. */
+int rtamd_render(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ,
+                 const rtamd_region* region, float* out_rgb, rtamd_stats* stats);
+int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ,
+                        const rtamd_region* region, float* out_rgb_device, rtamd_stats* stats);
+
+/* render::parallel_render_image quantiser (src/render.rs:62-72): floor(c*256) clamped to [0,255],
+ * on device memory, n = number of floats. */
+int rtamd_quantize_device(rtamd_context* ctx, const float* rgb_device, size_t n, uint8_t* out_device);
+
+/* Tuning / introspection. */
+enum rtamd_option {
+    RTAMD_OPT_PROFILE = 0,      /* 1: time each stage with HIP events (slower; fills *_ms) */
+    RTAMD_OPT_MAX_PATHS = 1,    /* pixels processed per wavefront chunk */
+    RTAMD_OPT_LDS_SCENE = 2     /* 1 (default): stage small meshes in LDS; 0: always read through L2 */
+};
+int rtamd_set_option(rtamd_context* ctx, int option, int64_t value);
+/* Average duration (ms) and launch count of the closest-hit / any-hit trace kernels since the last
+ * reset, measured with HIP events on the stream the kernels ran on (needs RTAMD_OPT_PROFILE). */
+int rtamd_kernel_times(rtamd_context* ctx, double* closest_ms_total, uint64_t* closest_launches,
+                       double* any_ms_total, uint64_t* any_launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

@@ -1,0 +1,627 @@
+// C ABI of the MI355X render hot path (declarations and reference citations: include/rtamd.h).
+// Host side only: context, scene upload (reference layout -> device layout), launch sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+#include "rtamd.h"
+
+using namespace rtamd;
+
+struct rtamd_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    LaunchCfg cfg;
+    bool profile = false;
+    size_t max_paths = (size_t)1 << 22;
+
+    // scene
+    bool have_scene = false;
+    DevScene S{};
+    std::vector<void*> scene_allocs;
+    uint32_t total_samples_lights = 0;   // not used on the host; kept for introspection
+    std::vector<rtamd_light> lights;
+
+    // wavefront workspace
+    WaveBufs W{};
+    std::vector<void*> wave_allocs;
+    size_t wave_cap = 0;
+    uint32_t wave_samples = 0;
+
+    // ray batch workspace of the host-pointer entry points
+    void* batch_buf = nullptr;
+    size_t batch_bytes = 0;
+
+    // kernel timing (RTAMD_OPT_PROFILE)
+    double closest_ms = 0, any_ms = 0, shade_ms = 0;
+    uint64_t closest_launches = 0, any_launches = 0;
+    struct Timed { hipEvent_t a, b; int kind; };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(rtamd_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, RTAMD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void free_list(std::vector<void*>& v) {
+    for (void* p : v) (void)hipFree(p);
+    v.clear();
+}
+
+template <class T>
+int upload_vec(rtamd_context* ctx, const std::vector<T>& host, const T** dev) {
+    size_t bytes = host.size() * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, bytes ? bytes : 16));
+    ctx->scene_allocs.push_back(p);
+    if (bytes) HIP_TRY(ctx, hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice));
+    *dev = (const T*)p;
+    return RTAMD_OK;
+}
+
+// Reference layout (AABB, skip, first) + sentinel  ->  device nodes (see rt_device.h).
+int convert_tree(rtamd_context* ctx, const rtamd_bvh_node* nodes, uint32_t n_nodes, uint32_t n_prims, const char* what,
+                 std::vector<float4>& out) {
+    if (nodes == nullptr || n_nodes < 2) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": a tree needs at least one node and the sentinel");
+    uint32_t n = n_nodes - 1;
+    if (nodes[n].first != n_prims) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": sentinel.first must equal the primitive count");
+    for (uint32_t i = 0; i < n; i++) {
+        const rtamd_bvh_node& nd = nodes[i];
+        uint32_t first = nd.first, end = nodes[i + 1].first;
+        if (nd.skip <= i || nd.skip > n) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": skip link must point forward and inside the tree");
+        if (first > end || end > n_prims) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": primitive range out of order");
+        bool leaf = nd.skip == i + 1;
+        if (!leaf && first != end) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": inner node with a primitive range");
+        uint32_t A = leaf ? (LEAF_BIT | first) : nd.skip;
+        uint32_t B = leaf ? end : 0u;
+        if (leaf && (first & LEAF_BIT)) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": too many primitives");
+        float fa, fb;
+        std::memcpy(&fa, &A, 4);
+        std::memcpy(&fb, &B, 4);
+        out.push_back(make_float4(nd.min[0], nd.min[1], nd.min[2], nd.max[0]));
+        out.push_back(make_float4(nd.max[1], nd.max[2], fa, fb));
+    }
+    return RTAMD_OK;
+}
+
+int ensure_batch(rtamd_context* ctx, size_t bytes) {
+    if (ctx->batch_bytes >= bytes) return RTAMD_OK;
+    if (ctx->batch_buf) (void)hipFree(ctx->batch_buf);
+    ctx->batch_buf = nullptr; ctx->batch_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->batch_buf, bytes));
+    ctx->batch_bytes = bytes;
+    return RTAMD_OK;
+}
+
+uint32_t light_samples(const rtamd_light& l, int shadow_rays) {
+    bool delta = l.kind == RTAMD_LIGHT_AMBIENT || (l.kind == RTAMD_LIGHT_POINT && l.param == 0.0f) ||
+                 (l.kind == RTAMD_LIGHT_DIRECTION && l.param > 0.0f);
+    return delta ? 1u : (uint32_t)(shadow_rays > 0 ? shadow_rays : 0);
+}
+
+template <class T>
+int wave_alloc(rtamd_context* ctx, T** p, size_t count) {
+    void* q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, count * sizeof(T) + 256));
+    ctx->wave_allocs.push_back(q);
+    *p = (T*)q;
+    return RTAMD_OK;
+}
+
+int ensure_wave(rtamd_context* ctx, size_t cap, uint32_t samples) {
+    if (ctx->wave_cap >= cap && ctx->wave_samples >= samples) return RTAMD_OK;
+    free_list(ctx->wave_allocs);
+    ctx->wave_cap = 0; ctx->wave_samples = 0;
+    WaveBufs& W = ctx->W;
+    int rc;
+    W.cap = (uint32_t)cap;
+    if ((rc = wave_alloc(ctx, &W.rng_lo, cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.rng_hi, cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.sum, 3 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.L, 3 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.beta, 3 * cap))) return rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = wave_alloc(ctx, &W.q_slot[k], cap))) return rc;
+        if ((rc = wave_alloc(ctx, &W.q_ray[k], 6 * cap))) return rc;
+    }
+    if ((rc = wave_alloc(ctx, &W.h_mat, cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.h_f, 8 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.lit_slot, cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.lit_f, 9 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.smp, (size_t)7 * (samples ? samples : 1) * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.counts, (size_t)16))) return rc;
+    if ((rc = wave_alloc(ctx, &W.stats, (size_t)16))) return rc;
+    ctx->wave_cap = cap; ctx->wave_samples = samples;
+    return RTAMD_OK;
+}
+
+hipEvent_t get_event(rtamd_context* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void timed_begin(rtamd_context* ctx, int kind, hipStream_t st) {
+    if (!ctx->profile) return;
+    rtamd_context::Timed t{get_event(ctx), get_event(ctx), kind};
+    (void)hipEventRecord(t.a, st);
+    ctx->timed.push_back(t);
+}
+void timed_end(rtamd_context* ctx, hipStream_t st) {
+    if (!ctx->profile) return;
+    (void)hipEventRecord(ctx->timed.back().b, st);
+}
+// Call after the stream is synchronised.
+void timed_collect(rtamd_context* ctx, rtamd_stats* stats) {
+    double c = 0, a = 0, s = 0;
+    for (auto& t : ctx->timed) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, t.a, t.b);
+        if (t.kind == 0) { c += ms; ctx->closest_launches++; }
+        else if (t.kind == 1) { a += ms; ctx->any_launches++; }
+        else s += ms;
+        ctx->event_pool.push_back(t.a);
+        ctx->event_pool.push_back(t.b);
+    }
+    ctx->timed.clear();
+    ctx->closest_ms += c; ctx->any_ms += a; ctx->shade_ms += s;
+    if (stats) { stats->trace_closest_ms = c; stats->trace_any_ms = a; stats->shade_ms = s; }
+}
+
+RegionDev make_region(const rtamd_region& r) {
+    RegionDev R;
+    R.x0 = r.x0; R.y0 = r.y0; R.w = r.w; R.h = r.h;
+    R.tile_w = r.tile_w; R.tile_h = r.tile_h; R.tile_first = r.tile_first; R.tile_stride = r.tile_stride;
+    R.tiles_x = (r.w + r.tile_w - 1) / r.tile_w;
+    uint32_t tiles_y = (r.h + r.tile_h - 1) / r.tile_h;
+    R.n_tiles = R.tiles_x * tiles_y;
+    return R;
+}
+bool region_ok(const rtamd_region* r) {
+    return r && r->w > 0 && r->h > 0 && r->tile_w > 0 && r->tile_h > 0 && r->tile_stride > 0 && r->tile_first < r->tile_stride;
+}
+size_t owned_tiles(const rtamd_region& r) {
+    size_t tiles_x = (r.w + r.tile_w - 1) / r.tile_w, tiles_y = (r.h + r.tile_h - 1) / r.tile_h;
+    size_t n = tiles_x * tiles_y;
+    if (r.tile_first >= n) return 0;
+    return (n - r.tile_first + r.tile_stride - 1) / r.tile_stride;
+}
+// valid (inside-rectangle) pixels among the owned tiles
+uint64_t owned_pixels(const rtamd_region& r) {
+    uint64_t tiles_x = (r.w + r.tile_w - 1) / r.tile_w, tiles_y = (r.h + r.tile_h - 1) / r.tile_h;
+    uint64_t n = tiles_x * tiles_y, px = 0;
+    for (uint64_t t = r.tile_first; t < n; t += r.tile_stride) {
+        uint64_t ty = t / tiles_x, tx = t % tiles_x;
+        uint64_t w = std::min<uint64_t>(r.tile_w, r.w - tx * r.tile_w), h = std::min<uint64_t>(r.tile_h, r.h - ty * r.tile_h);
+        px += w * h;
+    }
+    return px;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtamd_create(int device_id, rtamd_context** out) {
+    if (!out) return RTAMD_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return RTAMD_E_DEVICE;
+    rtamd_context* ctx = new rtamd_context();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RTAMD_E_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->cfg.num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return RTAMD_OK;
+}
+
+void rtamd_destroy(rtamd_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_list(ctx->scene_allocs);
+    free_list(ctx->wave_allocs);
+    if (ctx->batch_buf) (void)hipFree(ctx->batch_buf);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rtamd_last_error(const rtamd_context* ctx) { return ctx ? ctx->error.c_str() : "no context"; }
+
+int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
+    if (!ctx) return RTAMD_E_INVALID;
+    switch (option) {
+        case RTAMD_OPT_PROFILE: ctx->profile = value != 0; return RTAMD_OK;
+        case RTAMD_OPT_MAX_PATHS:
+            if (value < 64) return fail(ctx, RTAMD_E_INVALID, "max_paths must be >= 64");
+            ctx->max_paths = (size_t)value;
+            return RTAMD_OK;
+        case RTAMD_OPT_LDS_SCENE: ctx->cfg.use_lds = value != 0; return RTAMD_OK;
+        default: return fail(ctx, RTAMD_E_INVALID, "unknown option");
+    }
+}
+
+int rtamd_kernel_times(rtamd_context* ctx, double* closest_ms_total, uint64_t* closest_launches, double* any_ms_total,
+                       uint64_t* any_launches, int reset) {
+    if (!ctx) return RTAMD_E_INVALID;
+    if (closest_ms_total) *closest_ms_total = ctx->closest_ms;
+    if (closest_launches) *closest_launches = ctx->closest_launches;
+    if (any_ms_total) *any_ms_total = ctx->any_ms;
+    if (any_launches) *any_launches = ctx->any_launches;
+    if (reset) { ctx->closest_ms = ctx->any_ms = ctx->shade_ms = 0; ctx->closest_launches = ctx->any_launches = 0; }
+    return RTAMD_OK;
+}
+
+int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
+    if (!ctx || !sc) return RTAMD_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_list(ctx->scene_allocs);
+    ctx->have_scene = false;
+    if (sc->n_root == 0 || !sc->root) return fail(ctx, RTAMD_E_INVALID, "scene root is empty");
+    if (sc->n_objects == 0 || !sc->objects) return fail(ctx, RTAMD_E_INVALID, "scene has no objects");
+    if (sc->n_materials == 0 || !sc->materials) return fail(ctx, RTAMD_E_INVALID, "scene has no materials");
+
+    std::vector<float4> nodes, tris, normals;
+    std::vector<DevMesh> meshes;
+    std::vector<DevTree> trees;
+    int rc;
+    for (uint32_t m = 0; m < sc->n_meshes; m++) {
+        const rtamd_mesh& me = sc->meshes[m];
+        if (!me.tri_indices || !me.vertices || !me.normals) return fail(ctx, RTAMD_E_INVALID, "mesh with null arrays");
+        DevMesh dm;
+        dm.node_base = (uint32_t)(nodes.size() / 2);
+        dm.n_nodes = me.n_nodes ? me.n_nodes - 1 : 0;
+        dm.tri_base = (uint32_t)(tris.size() / 3);
+        dm.normal_base = (uint32_t)normals.size();
+        if ((rc = convert_tree(ctx, me.nodes, me.n_nodes, me.n_tris, "mesh tree", nodes))) return rc;
+        for (uint32_t k = 0; k < me.n_tris; k++) {
+            uint32_t i0 = me.tri_indices[3 * k], i1 = me.tri_indices[3 * k + 1], i2 = me.tri_indices[3 * k + 2];
+            if (i0 >= me.n_verts || i1 >= me.n_verts || i2 >= me.n_verts) return fail(ctx, RTAMD_E_INVALID, "triangle vertex index out of bounds");
+            const float *a = me.vertices + 3 * (size_t)i0, *b = me.vertices + 3 * (size_t)i1, *c = me.vertices + 3 * (size_t)i2;
+            // ab = b - a, ac = c - a: src/geom/triangle.rs:21-22, hoisted out of the per-ray work
+            float ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+            float ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            float f0, f1, f2;
+            std::memcpy(&f0, &i0, 4); std::memcpy(&f1, &i1, 4); std::memcpy(&f2, &i2, 4);
+            tris.push_back(make_float4(a[0], a[1], a[2], ab[0]));
+            tris.push_back(make_float4(ab[1], ab[2], ac[0], ac[1]));
+            tris.push_back(make_float4(ac[2], f0, f1, f2));
+        }
+        for (uint32_t v = 0; v < me.n_verts; v++)
+            normals.push_back(make_float4(me.normals[3 * (size_t)v], me.normals[3 * (size_t)v + 1], me.normals[3 * (size_t)v + 2], 0.0f));
+        meshes.push_back(dm);
+    }
+    for (uint32_t t = 0; t < sc->n_trees; t++) {
+        const rtamd_object_tree& tr = sc->trees[t];
+        if ((uint64_t)tr.first_object + tr.n_objects > sc->n_objects) return fail(ctx, RTAMD_E_INVALID, "object tree range outside objects[]");
+        DevTree dt;
+        dt.node_base = (uint32_t)(nodes.size() / 2);
+        dt.n_nodes = tr.n_nodes ? tr.n_nodes - 1 : 0;
+        dt.first_object = tr.first_object;
+        dt.pad = 0;
+        if ((rc = convert_tree(ctx, tr.nodes, tr.n_nodes, tr.n_objects, "object tree", nodes))) return rc;
+        trees.push_back(dt);
+    }
+    std::vector<DevObject> objects;
+    for (uint32_t o = 0; o < sc->n_objects; o++) {
+        const rtamd_object& ob = sc->objects[o];
+        if (ob.material >= sc->n_materials) return fail(ctx, RTAMD_E_INVALID, "object material index out of bounds");
+        if ((uint64_t)ob.op_first + ob.op_count > sc->n_ops) return fail(ctx, RTAMD_E_INVALID, "object op range out of bounds");
+        switch (ob.geom_kind) {
+            case RTAMD_GEOM_MESH: if (ob.geom_index >= sc->n_meshes) return fail(ctx, RTAMD_E_INVALID, "object mesh index out of bounds"); break;
+            case RTAMD_GEOM_CUBOID: if (ob.geom_index >= sc->n_cuboids) return fail(ctx, RTAMD_E_INVALID, "object cuboid index out of bounds"); break;
+            case RTAMD_GEOM_TRIANGLE: if (ob.geom_index >= sc->n_triangles) return fail(ctx, RTAMD_E_INVALID, "object triangle index out of bounds"); break;
+            case RTAMD_GEOM_UNIT_SPHERE: case RTAMD_GEOM_UNIT_CUBOID: break;
+            default: return fail(ctx, RTAMD_E_INVALID, "unknown geometry kind");
+        }
+        DevObject d{};
+        d.geom_kind = ob.geom_kind; d.geom_index = ob.geom_index; d.material = ob.material;
+        d.op_first = ob.op_first; d.op_count = ob.op_count;
+        objects.push_back(d);
+    }
+    std::vector<DevOp> ops;
+    for (uint32_t k = 0; k < sc->n_ops; k++) {
+        if (sc->ops[k].kind > RTAMD_OP_ROTATE) return fail(ctx, RTAMD_E_INVALID, "unknown transform op");
+        DevOp d{};
+        d.kind = sc->ops[k].kind;
+        std::memcpy(d.v, sc->ops[k].v, sizeof(d.v));
+        ops.push_back(d);
+    }
+    std::vector<DevRootItem> root;
+    for (uint32_t k = 0; k < sc->n_root; k++) {
+        const rtamd_root_item& it = sc->root[k];
+        if (it.kind == RTAMD_ROOT_OBJECT) { if (it.index >= sc->n_objects) return fail(ctx, RTAMD_E_INVALID, "root object index out of bounds"); }
+        else if (it.kind == RTAMD_ROOT_OBJECT_TREE) { if (it.index >= sc->n_trees) return fail(ctx, RTAMD_E_INVALID, "root tree index out of bounds"); }
+        else return fail(ctx, RTAMD_E_INVALID, "unknown root item kind");
+        root.push_back(DevRootItem{it.kind, it.index});
+    }
+    std::vector<DevCuboid> cuboids;
+    for (uint32_t k = 0; k < sc->n_cuboids; k++) {
+        DevCuboid d{};
+        std::memcpy(d.center, sc->cuboids[k].center, 12); std::memcpy(d.extent, sc->cuboids[k].extent, 12);
+        std::memcpy(d.inv_extent, sc->cuboids[k].inv_extent, 12);
+        cuboids.push_back(d);
+    }
+    std::vector<DevTriangle> triangles;
+    for (uint32_t k = 0; k < sc->n_triangles; k++) {
+        DevTriangle d{};
+        std::memcpy(d.a, sc->triangles[k].a, 12); std::memcpy(d.b, sc->triangles[k].b, 12); std::memcpy(d.c, sc->triangles[k].c, 12);
+        triangles.push_back(d);
+    }
+    std::vector<DevMaterial> materials;
+    for (uint32_t k = 0; k < sc->n_materials; k++) {
+        const rtamd_material& m = sc->materials[k];
+        if (m.kind > RTAMD_MAT_LAMBERT) return fail(ctx, RTAMD_E_INVALID, "unknown material kind");
+        DevMaterial d{};
+        d.kind = m.kind; d.p0 = m.p0; d.p1 = m.p1; std::memcpy(d.color, m.color, 12);
+        materials.push_back(d);
+    }
+    std::vector<DevLight> lights;
+    ctx->lights.clear();
+    for (uint32_t k = 0; k < sc->n_lights; k++) {
+        const rtamd_light& l = sc->lights[k];
+        if (l.kind == RTAMD_LIGHT_POINT) return fail(ctx, RTAMD_E_UNSUPPORTED, "point lights are not supported on the device yet");
+        if (l.kind > RTAMD_LIGHT_AO) return fail(ctx, RTAMD_E_INVALID, "unknown light kind");
+        DevLight d{};
+        d.kind = l.kind; std::memcpy(d.vec, l.vec, 12); d.param = l.param; std::memcpy(d.emission, l.emission, 12);
+        lights.push_back(d);
+        ctx->lights.push_back(l);
+    }
+    // skybox: RGB8 -> one RGBA8 word per texel (texture.rs:75-81 reads p[0..2])
+    std::vector<uint32_t> sky;
+    uint32_t sw = sc->sky_w, sh = sc->sky_h;
+    if (sc->skybox_rgb && sw && sh) {
+        sky.resize((size_t)sw * sh);
+        const uint8_t* p = sc->skybox_rgb;
+        for (size_t k = 0; k < sky.size(); k++) sky[k] = (uint32_t)p[3 * k] | ((uint32_t)p[3 * k + 1] << 8) | ((uint32_t)p[3 * k + 2] << 16) | 0xFF000000u;
+    } else {
+        sw = sh = 1;
+        sky.assign(1, 0xFF808080u);
+    }
+
+    DevScene S{};
+    if ((rc = upload_vec(ctx, nodes, &S.nodes))) return rc;
+    if ((rc = upload_vec(ctx, tris, &S.tris))) return rc;
+    if ((rc = upload_vec(ctx, normals, &S.normals))) return rc;
+    if ((rc = upload_vec(ctx, meshes, &S.meshes))) return rc;
+    if ((rc = upload_vec(ctx, trees, &S.trees))) return rc;
+    if ((rc = upload_vec(ctx, cuboids, &S.cuboids))) return rc;
+    if ((rc = upload_vec(ctx, triangles, &S.triangles))) return rc;
+    if ((rc = upload_vec(ctx, ops, &S.ops))) return rc;
+    if ((rc = upload_vec(ctx, objects, &S.objects))) return rc;
+    if ((rc = upload_vec(ctx, root, &S.root))) return rc;
+    if ((rc = upload_vec(ctx, materials, &S.materials))) return rc;
+    if ((rc = upload_vec(ctx, lights, &S.lights))) return rc;
+    if ((rc = upload_vec(ctx, sky, &S.sky))) return rc;
+    S.n_root = sc->n_root; S.n_lights = sc->n_lights; S.sky_w = sw; S.sky_h = sh;
+    S.n_objects = sc->n_objects; S.n_meshes = sc->n_meshes;
+    // LDS staging: the first mesh whose nodes + triangles fit in 52 KiB (three 512-thread blocks per CU)
+    S.lds_mesh = MISS; S.lds_bytes = 0;
+    for (uint32_t m = 0; m < sc->n_meshes; m++) {
+        size_t bytes = (size_t)meshes[m].n_nodes * 32 + (size_t)sc->meshes[m].n_tris * 48;
+        if (bytes > 0 && bytes <= 52 * 1024) { S.lds_mesh = m; S.lds_bytes = (uint32_t)bytes; break; }
+    }
+    ctx->S = S;
+    ctx->have_scene = true;
+    return RTAMD_OK;
+}
+
+int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream) {
+    if (!ctx || !rays || !out) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
+    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_E_INVALID, "at most 2^32-1 rays per call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
+    HitBatch hb{out->obj, out->prim, out->t, out->u, out->v};
+    timed_begin(ctx, 0, st);
+    HIP_TRY(ctx, launch_trace_closest(ctx->S, ctx->cfg, rb, hb, n, st));
+    timed_end(ctx, st);
+    if (!stream) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        timed_collect(ctx, nullptr);
+    }
+    return RTAMD_OK;
+}
+
+int rtamd_trace_any_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out, void* stream) {
+    if (!ctx || !rays || !out) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
+    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_E_INVALID, "at most 2^32-1 rays per call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
+    timed_begin(ctx, 1, st);
+    HIP_TRY(ctx, launch_trace_any(ctx->S, ctx->cfg, rb, out, n, st));
+    timed_end(ctx, st);
+    if (!stream) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        timed_collect(ctx, nullptr);
+    }
+    return RTAMD_OK;
+}
+
+int rtamd_trace_closest(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out) {
+    if (!ctx || !rays || !out) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
+    if (n == 0) return RTAMD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_batch(ctx, n * 12 * 4);
+    if (rc) return rc;
+    float* d = (float*)ctx->batch_buf;
+    const float* src[7] = {rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
+    for (int k = 0; k < 7; k++) HIP_TRY(ctx, hipMemcpyAsync(d + k * n, src[k], n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rtamd_rays dr{d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n, d + 6 * n};
+    rtamd_hits dh{(uint32_t*)(d + 7 * n), (uint32_t*)(d + 8 * n), d + 9 * n, d + 10 * n, d + 11 * n};
+    rc = rtamd_trace_closest_device(ctx, &dr, n, &dh, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(out->obj, dh.obj, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->prim, dh.prim, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->t, dh.t, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->u, dh.u, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out->v, dh.v, n * 4, hipMemcpyDeviceToHost));
+    return RTAMD_OK;
+}
+
+int rtamd_trace_any(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out) {
+    if (!ctx || !rays || !out) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
+    if (n == 0) return RTAMD_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_batch(ctx, n * 8 * 4);
+    if (rc) return rc;
+    float* d = (float*)ctx->batch_buf;
+    const float* src[7] = {rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
+    for (int k = 0; k < 7; k++) HIP_TRY(ctx, hipMemcpyAsync(d + k * n, src[k], n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rtamd_rays dr{d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n, d + 6 * n};
+    uint8_t* dout = (uint8_t*)(d + 7 * n);
+    rc = rtamd_trace_any_device(ctx, &dr, n, dout, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(out, dout, n, hipMemcpyDeviceToHost));
+    return RTAMD_OK;
+}
+
+size_t rtamd_region_pixels(const rtamd_region* region) {
+    if (!region_ok(region)) return 0;
+    return owned_tiles(*region) * (size_t)region->tile_w * region->tile_h;
+}
+
+int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region,
+                        float* out, rtamd_stats* stats) {
+    if (!ctx || !cam || !integ || !out) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
+    if (!region_ok(region)) return fail(ctx, RTAMD_E_INVALID, "bad region");
+    if (region->x0 + (uint64_t)region->w > cam->width || region->y0 + (uint64_t)region->h > cam->height)
+        return fail(ctx, RTAMD_E_INVALID, "region exceeds the camera image");
+    if (integ->antialiasing < 1) return fail(ctx, RTAMD_E_INVALID, "antialiasing must be >= 1");
+    if (integ->scatter_rays != 1) return fail(ctx, RTAMD_E_UNSUPPORTED, "only scatter_rays = 1 is supported on the device");
+    if (integ->shadow_rays < 1) return fail(ctx, RTAMD_E_INVALID, "shadow_rays must be >= 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    uint32_t S_total = 0;
+    for (const auto& l : ctx->lights) S_total += light_samples(l, integ->shadow_rays);
+    const size_t total_slots = rtamd_region_pixels(region);
+    if (total_slots == 0) return RTAMD_OK;
+    if (total_slots > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "region too large");
+    const size_t cap = std::min(total_slots, ctx->max_paths);
+    int rc = ensure_wave(ctx, cap, S_total);
+    if (rc) return rc;
+    WaveBufs W = ctx->W;
+    W.cap = (uint32_t)ctx->wave_cap;
+    hipStream_t st = ctx->stream;
+    RegionDev R = make_region(*region);
+    CameraDev C;
+    C.pos = f3{cam->pos[0], cam->pos[1], cam->pos[2]};
+    C.dir = f3{cam->dir[0], cam->dir[1], cam->dir[2]};
+    C.horizontal = f3{cam->horizontal[0], cam->horizontal[1], cam->horizontal[2]};
+    C.vertical = f3{cam->vertical[0], cam->vertical[1], cam->vertical[2]};
+    C.width = cam->width; C.height = cam->height;
+
+    hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(W.stats, 0, 32, st));
+    HIP_TRY(ctx, hipEventRecord(ev0, st));
+    uint64_t launches = 0;
+    const uint32_t aa = (uint32_t)integ->antialiasing;
+    for (size_t begin = 0; begin < total_slots; begin += cap) {
+        const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
+        for (uint32_t si = 0; si < aa; si++) {
+            for (uint32_t sj = 0; sj < aa; sj++) {
+                HIP_TRY(ctx, hipMemsetAsync(W.counts, 0, 16, st));
+                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, si == 0 && sj == 0, st));
+                launches++;
+                uint32_t cur = 0;
+                if (integ->max_depth <= 0) {
+                    HIP_TRY(ctx, launch_mark_miss(W, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, 0, 1, integ->shadow_rays, chunk_n, st));
+                    launches += 2;
+                }
+                for (int depth = 0; depth < integ->max_depth; depth++) {
+                    timed_begin(ctx, 0, st);
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, chunk_n, st));
+                    timed_end(ctx, st);
+                    timed_begin(ctx, 2, st);
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, depth, integ->max_depth, integ->shadow_rays, chunk_n, st));
+                    timed_end(ctx, st);
+                    timed_begin(ctx, 1, st);
+                    HIP_TRY(ctx, launch_wave_shadow(ctx->S, ctx->cfg, W, integ->shadow_rays, chunk_n, st));
+                    timed_end(ctx, st);
+                    launches += 3;
+                    cur ^= 1;
+                }
+            }
+        }
+        HIP_TRY(ctx, launch_finalize(W, R, (uint32_t)begin, chunk_n, (float)(aa * aa), out, st));
+        launches++;
+    }
+    HIP_TRY(ctx, hipEventRecord(ev1, st));
+    uint64_t hstats[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(hstats, W.stats, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    ctx->event_pool.push_back(ev0);
+    ctx->event_pool.push_back(ev1);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->closest_rays = hstats[0];
+        stats->any_rays = hstats[1];
+        stats->paths = owned_pixels(*region) * (uint64_t)aa * aa;
+        stats->launches = launches;
+        stats->device_ms = ms;
+    }
+    timed_collect(ctx, stats);
+    return RTAMD_OK;
+}
+
+int rtamd_render(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, float* out,
+                 rtamd_stats* stats) {
+    if (!ctx || !out) return RTAMD_E_INVALID;
+    size_t px = rtamd_region_pixels(region);
+    if (px == 0) return fail(ctx, RTAMD_E_INVALID, "bad region");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, px * 12));
+    int rc = rtamd_render_device(ctx, cam, integ, region, d, stats);
+    if (rc == RTAMD_OK) {
+        hipError_t e = hipMemcpy(out, d, px * 12, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, RTAMD_E_DEVICE, hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int rtamd_quantize_device(rtamd_context* ctx, const float* rgb, size_t n, uint8_t* out) {
+    if (!ctx || !rgb || !out) return RTAMD_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_quantize(rgb, n, out, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RTAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,491 @@
+// Device-side scene layout, exact-order float helpers and the traversal / intersection routines of
+// the MI355X render hot path.  Compiled for gfx950 only, with -ffp-contract=off: every float
+// operation below is one IEEE binary32 operation, written in the order the reference performs it,
+// so hits (object, primitive, t, u, v) are bit-identical to the CPU renderer's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtamd {
+
+// ------------------------------------------------------------------------------------------------
+// Device scene layout (HBM).  All trees share one node array, all meshes one triangle array.
+//
+//   nodes   : 32 B per node = 2 x float4: {min.x min.y min.z max.x} {max.y max.z A B}
+//             inner node: A = skip index (relative to the tree), B = 0
+//             leaf node : A = LEAF_BIT | first, B = end  (primitive range in tree order; skip = i+1)
+//             The reference stores (AABB, skip, first) and reads the next node's `first` as the end
+//             of the range (src/geom/bvh.rs:7,232-233); a leaf's skip is always i+1 because it has
+//             no children (bvh.rs:148), and an inner node's range is empty, so one word per case
+//             is enough and the dependent load of nodes[i+1] disappears.
+//   tris    : 48 B per triangle = 3 x float4: {a.x a.y a.z ab.x} {ab.y ab.z ac.x ac.y} {ac.z i j k}
+//             ab = b - a and ac = c - a are the first two operations of moller_trumbore
+//             (src/geom/triangle.rs:21-22) and do not depend on the ray, so they are done once on
+//             upload; i,j,k are the vertex indices (bit patterns) for the normal lookup.
+//   normals : one float4 per vertex.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t LEAF_BIT = 0x80000000u;
+static constexpr uint32_t MISS = 0xFFFFFFFFu;
+
+struct DevMesh { uint32_t node_base, n_nodes, tri_base, normal_base; };   // n_nodes excludes the sentinel
+struct DevTree { uint32_t node_base, n_nodes, first_object, pad; };
+struct DevCuboid { float center[3], extent[3], inv_extent[3]; float pad[3]; };
+struct DevTriangle { float a[3], b[3], c[3]; float pad[3]; };
+struct DevOp { uint32_t kind; float v[9]; uint32_t pad[2]; };
+struct DevObject { uint32_t geom_kind, geom_index, material, op_first, op_count, pad[3]; };
+struct DevRootItem { uint32_t kind, index; };
+struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t pad[2]; };
+struct DevLight { uint32_t kind; float vec[3]; float param; float emission[3]; };
+
+enum { OP_TRANSLATE = 0, OP_SCALE = 1, OP_ROTATE = 2 };
+enum { GEOM_MESH = 0, GEOM_UNIT_SPHERE = 1, GEOM_CUBOID = 2, GEOM_UNIT_CUBOID = 3, GEOM_TRIANGLE = 4 };
+enum { ROOT_OBJECT = 0, ROOT_TREE = 1 };
+enum { MAT_NULL = 0, MAT_METAL = 1, MAT_GLOSSY = 2, MAT_TRANSPARENT = 3, MAT_LAMBERT = 4 };
+enum { LIGHT_AMBIENT = 0, LIGHT_POINT = 1, LIGHT_DIRECTION = 2, LIGHT_AO = 3 };
+
+struct DevScene {
+    const float4* nodes;
+    const float4* tris;
+    const float4* normals;
+    const DevMesh* meshes;
+    const DevTree* trees;
+    const DevCuboid* cuboids;
+    const DevTriangle* triangles;
+    const DevOp* ops;
+    const DevObject* objects;
+    const DevRootItem* root;
+    const DevMaterial* materials;
+    const DevLight* lights;
+    const uint32_t* sky;  // RGBA8, one word per texel
+    uint32_t n_root, n_lights, sky_w, sky_h;
+    uint32_t n_objects, n_meshes;
+    uint32_t lds_mesh;        // mesh index staged in LDS by the trace kernels, or MISS
+    uint32_t lds_bytes;       // bytes of LDS needed for that mesh
+};
+
+// ------------------------------------------------------------------------------------------------
+// Exact-order float3 helpers (src/math/vec3d.rs:115-126,181-287).
+// ------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 fill(float s) { return mk(s, s, s); }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ f3 normalize(f3 a) {  // vec3d.rs:100-112
+    float len = sqrtf(dot(a, a));
+    if (len > 0.0f) return a / len;
+    return fill(__uint_as_float(0x7FC00000u));
+}
+__device__ __forceinline__ bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+// max!/min! compare-selects (src/common.rs:31-53); NOT fmaxf/fminf (different NaN behaviour).
+__device__ __forceinline__ float max2(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float min2(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ bool signbit32(float x) { return (__float_as_uint(x) >> 31) != 0u; }
+
+__device__ __forceinline__ void ortho_axes(f3 a, f3& b, f3& c) {  // vec3d.rs:128-141
+    if (fabsf(a.x) > fabsf(a.y)) {
+        float inv_len = 1.0f / sqrtf(a.x * a.x + a.z * a.z);
+        b = mk(-a.z * inv_len, 0.0f, a.x * inv_len);
+    } else {
+        float inv_len = 1.0f / sqrtf(a.y * a.y + a.z * a.z);
+        b = mk(0.0f, a.z * inv_len, -a.y * inv_len);
+    }
+    c = cross(a, b);
+}
+// Mat3D::apply / transpose_apply (src/math/mat3d.rs:139-169): accumulate from 0.0 in j order.
+__device__ __forceinline__ f3 mat_apply(const float* m, f3 a) {
+    f3 b;
+    b.x = ((0.0f + m[0] * a.x) + m[1] * a.y) + m[2] * a.z;
+    b.y = ((0.0f + m[3] * a.x) + m[4] * a.y) + m[5] * a.z;
+    b.z = ((0.0f + m[6] * a.x) + m[7] * a.y) + m[8] * a.z;
+    return b;
+}
+__device__ __forceinline__ f3 mat_transpose_apply(const float* m, f3 a) {
+    f3 b;
+    b.x = ((0.0f + m[0] * a.x) + m[3] * a.y) + m[6] * a.z;
+    b.y = ((0.0f + m[1] * a.x) + m[4] * a.y) + m[7] * a.z;
+    b.z = ((0.0f + m[2] * a.x) + m[5] * a.y) + m[8] * a.z;
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Memory accessors for the node / triangle arrays of one tree: global (L2/HBM) or LDS.
+// ------------------------------------------------------------------------------------------------
+struct GlobalMem {
+    const float4* nodes;
+    const float4* tris;
+    __device__ __forceinline__ void node(uint32_t i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
+    __device__ __forceinline__ void tri(uint32_t k, float4& q0, float4& q1, float4& q2) const {
+        q0 = tris[3 * k]; q1 = tris[3 * k + 1]; q2 = tris[3 * k + 2];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// AABB::fast_intersect_ray (src/math/aabb.rs:61-87) + the visit test of AABBTree::traverse
+// (src/geom/bvh.rs:230-231).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool node_passes(float4 n0, float4 n1, f3 pos, f3 inv, bool ngx, bool ngy, bool ngz, float t_max) {
+    float ax = (n0.x - pos.x) * inv.x, ay = (n0.y - pos.y) * inv.y, az = (n0.z - pos.z) * inv.z;
+    float bx = (n0.w - pos.x) * inv.x, by = (n1.x - pos.y) * inv.y, bz = (n1.y - pos.z) * inv.z;
+    float a0 = ngx ? bx : ax, b0 = ngx ? ax : bx;
+    float a1 = ngy ? by : ay, b1 = ngy ? ay : by;
+    float a2 = ngz ? bz : az, b2 = ngz ? az : bz;
+    float t0 = max2(a0, max2(a1, a2));
+    float t1 = min2(b0, min2(b1, b2));
+    return (t0 < t1) && (t0 <= t_max + 0.01f) && (t1 >= -0.01f);
+}
+
+// moller_trumbore (src/geom/triangle.rs:18-38) on the pre-subtracted edges, followed by the accept
+// test of MeshTriangle::hit (src/geom/mesh.rs:130).  A near-parallel ray (|det| < 1e-12) yields
+// t = u = v = 0, which the accept test lets through, exactly as the reference does.
+__device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
+    f3 a = mk(q0.x, q0.y, q0.z), ab = mk(q0.w, q1.x, q1.y), ac = mk(q1.z, q1.w, q2.x);
+    f3 pv = cross(dir, ac);
+    float det = dot(ab, pv);
+    if (fabsf(det) < 1e-12f) {
+        t = 0.0f; u = 0.0f; v = 0.0f;
+    } else {
+        float inv_det = 1.0f / det;
+        f3 tv = pos - a;
+        f3 qv = cross(tv, ab);
+        t = dot(qv, ac) * inv_det;
+        u = dot(tv, pv) * inv_det;
+        v = dot(qv, dir) * inv_det;
+    }
+    return t >= 0.0f && t <= t_max && u >= 0.0f && v >= 0.0f && u + v <= 1.0f;
+}
+
+// AABBTree<MeshTriangle>::hit / is_hit (src/geom/bvh.rs:207-281): stackless skip-link walk in the
+// reference's fixed left-first order.  Closest: t_max shrinks on every accepted triangle, a later
+// triangle with the same t replaces an earlier one (`t <= t_max`).  Any: constant t_max, first
+// accepted triangle ends the walk.
+template <bool ANY, class Mem>
+__device__ __forceinline__ bool traverse_mesh(const Mem& mem, uint32_t n_nodes, f3 pos, f3 dir, float& t_max,
+                                              uint32_t& prim, float& hu, float& hv) {
+    f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // bvh.rs:220 recomputes 1/dir
+    bool ngx = signbit32(inv.x), ngy = signbit32(inv.y), ngz = signbit32(inv.z);
+    bool found = false;
+    uint32_t i = 0;
+    while (i < n_nodes) {
+        float4 n0, n1;
+        mem.node(i, n0, n1);
+        uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
+        bool leaf = (A & LEAF_BIT) != 0u;
+        if (node_passes(n0, n1, pos, inv, ngx, ngy, ngz, t_max)) {
+            if (leaf) {
+                for (uint32_t k = A & ~LEAF_BIT; k < B; k++) {
+                    float4 q0, q1, q2;
+                    mem.tri(k, q0, q1, q2);
+                    float t, u, v;
+                    if (tri_test(q0, q1, q2, pos, dir, t_max, t, u, v)) {
+                        if (ANY) return true;
+                        t_max = t; prim = k; hu = u; hv = v; found = true;
+                    }
+                }
+            }
+            i += 1;
+        } else {
+            i = leaf ? i + 1 : A;
+        }
+    }
+    return found;
+}
+
+// sphere_intersect + UnitSphere::hit / is_hit (src/geom/sphere.rs:22-69).
+__device__ __forceinline__ bool sphere_roots(f3 pos, f3 dir, float& t0, float& t1) {
+    float a = -dot(dir, pos);
+    float b = a * a - dot(pos, pos) + 1.0f;
+    if (b >= 0.0f) {
+        float d = sqrtf(b);
+        t0 = a - d; t1 = a + d;
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ bool unit_sphere_hit(f3 pos, f3 dir, float t_max, float& t) {
+    float t0, t1;
+    if (!sphere_roots(pos, dir, t0, t1)) return false;
+    if (t0 >= 0.0f && t0 <= t_max) { t = t0; return true; }
+    if (t1 >= 0.0f && t1 <= t_max) { t = t1; return true; }
+    return false;
+}
+__device__ __forceinline__ bool unit_sphere_any(f3 pos, f3 dir, float t_max) {
+    float t0, t1;
+    if (sphere_roots(pos, dir, t0, t1)) return t0 <= t_max && t1 >= 0.0f;
+    return false;
+}
+
+// ray_box_intersection (src/geom/cuboid.rs:8-16): symmetric min!/max! form.
+__device__ __forceinline__ void box_roots(f3 pos, f3 inv_dir, f3 mn, f3 mx, float& t0, float& t1) {
+    f3 a = (mn - pos) * inv_dir;
+    f3 b = (mx - pos) * inv_dir;
+    t0 = max2(min2(a.x, b.x), max2(min2(a.y, b.y), min2(a.z, b.z)));
+    t1 = min2(max2(a.x, b.x), min2(max2(a.y, b.y), max2(a.z, b.z)));
+}
+// UnitCuboid::hit (cuboid.rs:19-48), t only.
+__device__ __forceinline__ bool unit_cuboid_hit(f3 pos, f3 dir, float t_max, float& t) {
+    f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);  // Ray::new, src/math/ray.rs:15
+    float t0, t1;
+    box_roots(pos, inv, fill(-1.0f), fill(1.0f), t0, t1);
+    if (t0 > t1 || t0 > t_max || t1 < 0.0f) return false;
+    t = (t0 > 0.0f) ? t0 : t1;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray-space wrappers going in (src/geom/transform.rs:57-58,104-106,178-180).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ops_in(const DevOp* __restrict__ ops, uint32_t first, uint32_t count, f3& pos, f3& dir, float& t_max) {
+    for (uint32_t k = 0; k < count; k++) {
+        const DevOp& op = ops[first + k];
+        if (op.kind == OP_TRANSLATE) {
+            pos = pos - mk(op.v[0], op.v[1], op.v[2]);
+        } else if (op.kind == OP_SCALE) {
+            pos = pos * op.v[1];
+            t_max = t_max * op.v[1];
+        } else {
+            pos = mat_transpose_apply(op.v, pos);
+            dir = mat_transpose_apply(op.v, dir);
+        }
+    }
+}
+// Hit distance coming back out: Scale multiplies t (transform.rs:107).
+__device__ __forceinline__ float ops_t_out(const DevOp* __restrict__ ops, uint32_t first, uint32_t count, float t) {
+    for (uint32_t k = count; k-- > 0;) {
+        const DevOp& op = ops[first + k];
+        if (op.kind == OP_SCALE) t = t * op.v[0];
+    }
+    return t;
+}
+// Hit position / normal coming back out (transform.rs:61,108,183-184).
+__device__ __forceinline__ void ops_hit_out(const DevOp* __restrict__ ops, uint32_t first, uint32_t count, f3& pos, f3& nrm) {
+    for (uint32_t k = count; k-- > 0;) {
+        const DevOp& op = ops[first + k];
+        if (op.kind == OP_TRANSLATE) {
+            pos = pos + mk(op.v[0], op.v[1], op.v[2]);
+        } else if (op.kind == OP_SCALE) {
+            pos = pos * op.v[0];
+        } else {
+            pos = mat_apply(op.v, pos);
+            nrm = mat_apply(op.v, nrm);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Closest-hit state of one ray.
+// ------------------------------------------------------------------------------------------------
+struct Best {
+    uint32_t obj, prim;
+    float t_local, u, v;
+};
+
+// Object::hit (src/geom/aggregate.rs:104-111) for the closest-hit query: returns true and shrinks
+// t_max (caller's space) when the object is hit within t_max.
+template <class Mem>
+__device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds_mem, uint32_t oi, f3 pos, f3 dir, float& t_max, Best& best) {
+    const DevObject ob = S.objects[oi];
+    float tl_max = t_max;
+    ops_in(S.ops, ob.op_first, ob.op_count, pos, dir, tl_max);
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    uint32_t prim = 0;
+    bool hit = false;
+    if (ob.geom_kind == GEOM_MESH) {
+        const DevMesh m = S.meshes[ob.geom_index];
+        if (lds_mem != nullptr && ob.geom_index == S.lds_mesh) {
+            hit = traverse_mesh<false>(*lds_mem, m.n_nodes, pos, dir, tl_max, prim, u, v);
+        } else {
+            GlobalMem gm{S.nodes + 2 * (size_t)m.node_base, S.tris + 3 * (size_t)m.tri_base};
+            hit = traverse_mesh<false>(gm, m.n_nodes, pos, dir, tl_max, prim, u, v);
+        }
+        t = tl_max;
+    } else if (ob.geom_kind == GEOM_UNIT_SPHERE) {
+        hit = unit_sphere_hit(pos, dir, tl_max, t);
+    } else if (ob.geom_kind == GEOM_CUBOID) {
+        const DevCuboid c = S.cuboids[ob.geom_index];
+        f3 ie = mk(c.inv_extent[0], c.inv_extent[1], c.inv_extent[2]);
+        f3 p = (pos - mk(c.center[0], c.center[1], c.center[2])) * ie;  // cuboid.rs:83-85
+        f3 d = dir * ie;
+        hit = unit_cuboid_hit(p, d, tl_max, t);
+    } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {
+        hit = unit_cuboid_hit(pos, dir, tl_max, t);
+    } else {  // GEOM_TRIANGLE (triangle.rs:41-57)
+        const DevTriangle tr = S.triangles[ob.geom_index];
+        f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
+        f3 ab = mk(tr.b[0], tr.b[1], tr.b[2]) - a, ac = mk(tr.c[0], tr.c[1], tr.c[2]) - a;
+        float4 q0 = make_float4(a.x, a.y, a.z, ab.x), q1 = make_float4(ab.y, ab.z, ac.x, ac.y), q2 = make_float4(ac.z, 0.f, 0.f, 0.f);
+        hit = tri_test(q0, q1, q2, pos, dir, tl_max, t, u, v);
+    }
+    if (hit) {
+        best.obj = oi; best.prim = prim; best.t_local = t; best.u = u; best.v = v;
+        t_max = ops_t_out(S.ops, ob.op_first, ob.op_count, t);
+    }
+    return hit;
+}
+
+// Object::is_hit (aggregate.rs:113-118) for the occlusion query.
+template <class Mem>
+__device__ __forceinline__ bool object_any(const DevScene& S, const Mem* lds_mem, uint32_t oi, f3 pos, f3 dir, float t_max) {
+    const DevObject ob = S.objects[oi];
+    ops_in(S.ops, ob.op_first, ob.op_count, pos, dir, t_max);
+    if (ob.geom_kind == GEOM_MESH) {
+        const DevMesh m = S.meshes[ob.geom_index];
+        uint32_t prim; float u, v;
+        if (lds_mem != nullptr && ob.geom_index == S.lds_mesh) {
+            return traverse_mesh<true>(*lds_mem, m.n_nodes, pos, dir, t_max, prim, u, v);
+        }
+        GlobalMem gm{S.nodes + 2 * (size_t)m.node_base, S.tris + 3 * (size_t)m.tri_base};
+        return traverse_mesh<true>(gm, m.n_nodes, pos, dir, t_max, prim, u, v);
+    } else if (ob.geom_kind == GEOM_UNIT_SPHERE) {
+        return unit_sphere_any(pos, dir, t_max);
+    } else if (ob.geom_kind == GEOM_CUBOID) {  // cuboid.rs:95-100: world-space slab with Ray::inv_dir
+        const DevCuboid c = S.cuboids[ob.geom_index];
+        f3 ctr = mk(c.center[0], c.center[1], c.center[2]), ext = mk(c.extent[0], c.extent[1], c.extent[2]);
+        f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        float t0, t1;
+        box_roots(pos, inv, ctr - ext, ctr + ext, t0, t1);
+        return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
+    } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {  // cuboid.rs:50-54
+        f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        float t0, t1;
+        box_roots(pos, inv, fill(-1.0f), fill(1.0f), t0, t1);
+        return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
+    } else {  // triangle.rs:59-62
+        const DevTriangle tr = S.triangles[ob.geom_index];
+        f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
+        f3 ab = mk(tr.b[0], tr.b[1], tr.b[2]) - a, ac = mk(tr.c[0], tr.c[1], tr.c[2]) - a;
+        float4 q0 = make_float4(a.x, a.y, a.z, ab.x), q1 = make_float4(ab.y, ab.z, ac.x, ac.y), q2 = make_float4(ac.z, 0.f, 0.f, 0.f);
+        float t, u, v;
+        return tri_test(q0, q1, q2, pos, dir, t_max, t, u, v);
+    }
+}
+
+// GeometryList::hit (src/geom/aggregate.rs:24-35) over the root items; an object tree item is
+// AABBTree<Object>::hit (src/geom/bvh.rs:259-269) in world space.
+template <class Mem>
+__device__ __forceinline__ bool scene_closest(const DevScene& S, const Mem* lds_mem, f3 pos, f3 dir, float t_max, Best& best, float& t_hit) {
+    bool found = false;
+    for (uint32_t r = 0; r < S.n_root; r++) {
+        const DevRootItem it = S.root[r];
+        if (it.kind == ROOT_OBJECT) {
+            found |= object_closest(S, lds_mem, it.index, pos, dir, t_max, best);
+        } else {
+            const DevTree tr = S.trees[it.index];
+            const float4* nodes = S.nodes + 2 * (size_t)tr.node_base;
+            f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+            bool ngx = signbit32(inv.x), ngy = signbit32(inv.y), ngz = signbit32(inv.z);
+            uint32_t i = 0;
+            while (i < tr.n_nodes) {
+                float4 n0 = nodes[2 * i], n1 = nodes[2 * i + 1];
+                uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
+                bool leaf = (A & LEAF_BIT) != 0u;
+                if (node_passes(n0, n1, pos, inv, ngx, ngy, ngz, t_max)) {
+                    if (leaf) {
+                        for (uint32_t k = A & ~LEAF_BIT; k < B; k++)
+                            found |= object_closest(S, lds_mem, tr.first_object + k, pos, dir, t_max, best);
+                    }
+                    i += 1;
+                } else {
+                    i = leaf ? i + 1 : A;
+                }
+            }
+        }
+    }
+    t_hit = t_max;
+    return found;
+}
+
+// GeometryList::is_hit (aggregate.rs:37-45) / AABBTree<Object>::is_hit (bvh.rs:271-281).
+template <class Mem>
+__device__ __forceinline__ bool scene_any(const DevScene& S, const Mem* lds_mem, f3 pos, f3 dir, float t_max) {
+    for (uint32_t r = 0; r < S.n_root; r++) {
+        const DevRootItem it = S.root[r];
+        if (it.kind == ROOT_OBJECT) {
+            if (object_any(S, lds_mem, it.index, pos, dir, t_max)) return true;
+        } else {
+            const DevTree tr = S.trees[it.index];
+            const float4* nodes = S.nodes + 2 * (size_t)tr.node_base;
+            f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+            bool ngx = signbit32(inv.x), ngy = signbit32(inv.y), ngz = signbit32(inv.z);
+            uint32_t i = 0;
+            while (i < tr.n_nodes) {
+                float4 n0 = nodes[2 * i], n1 = nodes[2 * i + 1];
+                uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
+                bool leaf = (A & LEAF_BIT) != 0u;
+                if (node_passes(n0, n1, pos, inv, ngx, ngy, ngz, t_max)) {
+                    if (leaf) {
+                        for (uint32_t k = A & ~LEAF_BIT; k < B; k++)
+                            if (object_any(S, lds_mem, tr.first_object + k, pos, dir, t_max)) return true;
+                    }
+                    i += 1;
+                } else {
+                    i = leaf ? i + 1 : A;
+                }
+            }
+        }
+    }
+    return false;
+}
+
+// HitResult{pos, norm, uv} of the winning primitive in the caller's space
+// (mesh.rs:131-143, sphere.rs:47-59, cuboid.rs:30-47,88, triangle.rs:45-51, then the wrappers
+// on the way out).  Needs the original ray; recomputes the object-space ray with the same
+// operations as the traversal did.
+__device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b, f3 pos, f3 dir, f3& hpos, f3& hnorm, float& hu, float& hv) {
+    const DevObject ob = S.objects[b.obj];
+    float dummy = 0.0f;
+    ops_in(S.ops, ob.op_first, ob.op_count, pos, dir, dummy);
+    f3 p, n;
+    hu = b.u; hv = b.v;
+    if (ob.geom_kind == GEOM_MESH) {
+        const DevMesh m = S.meshes[ob.geom_index];
+        float4 q2 = S.tris[3 * ((size_t)m.tri_base + b.prim) + 2];
+        const float4* nr = S.normals + m.normal_base;
+        float4 na = nr[__float_as_uint(q2.y)], nb = nr[__float_as_uint(q2.z)], nc = nr[__float_as_uint(q2.w)];
+        float w = 1.0f - b.u - b.v;
+        n = (w * mk(na.x, na.y, na.z) + b.u * mk(nb.x, nb.y, nb.z)) + b.v * mk(nc.x, nc.y, nc.z);
+        p = pos + fill(b.t_local) * dir;
+    } else if (ob.geom_kind == GEOM_UNIT_SPHERE) {
+        p = pos + fill(b.t_local) * dir;
+        n = p;
+        const float PI_F = 3.14159274101257324219f;
+        hu = atan2f(n.x, n.y) / PI_F * 0.5f + 0.5f;
+        hv = acosf(n.z) / PI_F;
+    } else if (ob.geom_kind == GEOM_CUBOID || ob.geom_kind == GEOM_UNIT_CUBOID) {
+        f3 lp = pos, ld = dir;
+        DevCuboid c;
+        if (ob.geom_kind == GEOM_CUBOID) {
+            c = S.cuboids[ob.geom_index];
+            f3 ie = mk(c.inv_extent[0], c.inv_extent[1], c.inv_extent[2]);
+            lp = (pos - mk(c.center[0], c.center[1], c.center[2])) * ie;
+            ld = dir * ie;
+        }
+        f3 q = lp + fill(b.t_local) * ld;
+        f3 qa = mk(fabsf(q.x), fabsf(q.y), fabsf(q.z));
+        if (qa.x > qa.y && qa.x > qa.z) { n = mk(q.x, 0.0f, 0.0f); hu = q.y; hv = q.z; }
+        else if (qa.y > qa.z) { n = mk(0.0f, q.y, 0.0f); hu = q.x; hv = q.z; }
+        else { n = mk(0.0f, 0.0f, q.z); hu = q.x; hv = q.y; }
+        p = q;
+        if (ob.geom_kind == GEOM_CUBOID)
+            p = q * mk(c.extent[0], c.extent[1], c.extent[2]) + mk(c.center[0], c.center[1], c.center[2]);
+    } else {
+        const DevTriangle tr = S.triangles[ob.geom_index];
+        f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
+        n = cross(mk(tr.b[0], tr.b[1], tr.b[2]) - a, mk(tr.c[0], tr.c[1], tr.c[2]) - a);
+        p = pos + fill(b.t_local) * dir;
+    }
+    ops_hit_out(S.ops, ob.op_first, ob.op_count, p, n);
+    hpos = p; hnorm = n;
+}
+
+}  // namespace rtamd

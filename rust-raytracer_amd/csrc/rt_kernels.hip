@@ -1,0 +1,605 @@
+// HIP kernels of the render hot path for MI355X (gfx950): batched closest-hit / any-hit tracing and
+// the wavefront form of the reference integrator (ray generation, trace, shade + light sampling +
+// skybox lookup, shadow trace, wave64 ballot compaction of the surviving paths).
+//
+// Work distribution: one lane = one ray / path.  Every queue-driven kernel is launched with a fixed
+// grid that covers the chip and walks its queue with a grid stride; the queue length is read from
+// device memory, so the host never synchronises inside a frame.
+#include "rt_kernels.h"
+
+namespace rtamd {
+
+// ------------------------------------------------------------------------------------------------
+// LDS staging of one small mesh (nodes + triangles): every block copies it once, then all its
+// waves traverse out of LDS instead of L1/L2.  ds_read_b128 per node half / triangle third.
+// ------------------------------------------------------------------------------------------------
+struct LdsMem {
+    const float4* nodes;
+    const float4* tris;
+    __device__ __forceinline__ void node(uint32_t i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
+    __device__ __forceinline__ void tri(uint32_t k, float4& q0, float4& q1, float4& q2) const {
+        q0 = tris[3 * k]; q1 = tris[3 * k + 1]; q2 = tris[3 * k + 2];
+    }
+};
+
+extern __shared__ float4 g_lds[];
+
+template <bool USE_LDS>
+__device__ __forceinline__ const LdsMem* stage_mesh(const DevScene& S, LdsMem& mem) {
+    if (!USE_LDS) return nullptr;
+    const DevMesh m = S.meshes[S.lds_mesh];
+    const uint32_t n_node4 = 2 * m.n_nodes;
+    const uint32_t n_tri4 = S.lds_bytes / 16 - n_node4;
+    const float4* gn = S.nodes + 2 * (size_t)m.node_base;
+    const float4* gt = S.tris + 3 * (size_t)m.tri_base;
+    for (uint32_t i = threadIdx.x; i < n_node4; i += blockDim.x) g_lds[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < n_tri4; i += blockDim.x) g_lds[n_node4 + i] = gt[i];
+    __syncthreads();
+    mem.nodes = g_lds;
+    mem.tris = g_lds + n_node4;
+    return &mem;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched Geometry::hit / is_hit on caller-provided ray arrays (the parity entry points).
+// ------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene S, RayBatch rays, HitBatch out, uint32_t n) {
+    LdsMem mem;
+    const LdsMem* lm = stage_mesh<USE_LDS>(S, mem);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        f3 pos = mk(rays.ox[i], rays.oy[i], rays.oz[i]);
+        f3 dir = mk(rays.dx[i], rays.dy[i], rays.dz[i]);
+        Best b;
+        b.obj = MISS; b.prim = 0; b.t_local = 0.f; b.u = 0.f; b.v = 0.f;
+        float t_hit;
+        bool found = scene_closest(S, lm, pos, dir, rays.tmax[i], b, t_hit);
+        float hu = 0.f, hv = 0.f;
+        if (found) {
+            f3 hp, hn;
+            reconstruct_hit(S, b, pos, dir, hp, hn, hu, hv);
+        }
+        out.obj[i] = found ? b.obj : MISS;
+        out.prim[i] = found ? b.prim : MISS;
+        out.t[i] = found ? t_hit : 0.0f;
+        out.u[i] = hu;
+        out.v[i] = hv;
+    }
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene S, RayBatch rays, uint8_t* out, uint32_t n) {
+    LdsMem mem;
+    const LdsMem* lm = stage_mesh<USE_LDS>(S, mem);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        f3 pos = mk(rays.ox[i], rays.oy[i], rays.oz[i]);
+        f3 dir = mk(rays.dx[i], rays.dy[i], rays.dz[i]);
+        out[i] = scene_any(S, lm, pos, dir, rays.tmax[i]) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rand 0.6 SmallRng on 64-bit targets = PCG Mcg128Xsl64, seeded through rand_core's
+// seed_from_u64 (PCG32 expansion).  State is the 128-bit MCG state as two 64-bit halves.
+// ------------------------------------------------------------------------------------------------
+struct Rng { uint64_t lo, hi; };
+__device__ __forceinline__ Rng rng_seed(uint64_t state) {
+    const uint64_t MUL = 6364136223846793005ULL, INC = 11634580027462260723ULL;
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        state = state * MUL + INC;
+        uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
+        uint32_t rot = (uint32_t)(state >> 59);
+        w[k] = (xs >> rot) | (xs << ((32 - rot) & 31));
+    }
+    Rng r;
+    r.lo = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) | 1ULL;
+    r.hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    return r;
+}
+__device__ __forceinline__ uint32_t rng_u32(Rng& r) {
+    const uint64_t MH = 0x2360ED051FC65DA4ULL, ML = 0x4385DF649FCCF645ULL;
+    uint64_t lo = r.lo * ML;
+    uint64_t hi = __umul64hi(r.lo, ML) + r.lo * MH + r.hi * ML;
+    r.lo = lo; r.hi = hi;
+    uint32_t rot = (uint32_t)(hi >> 58);
+    uint64_t xsl = hi ^ lo;
+    uint64_t o = (xsl >> rot) | (xsl << ((64 - rot) & 63));
+    return (uint32_t)o;
+}
+__device__ __forceinline__ float rng_f32(Rng& r) {  // Standard: 24 bits * 2^-24
+    return (1.0f / 16777216.0f) * (float)(rng_u32(r) >> 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shading helpers (src/material.rs, src/light.rs, src/scene.rs:16-21, src/texture.rs:70-82).
+// ------------------------------------------------------------------------------------------------
+static constexpr float PI_F = 3.14159274101257324219f;
+
+__device__ __forceinline__ float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+__device__ __forceinline__ float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+__device__ __forceinline__ f3 sky_color(const DevScene& S, f3 d) {
+    float u = atan2f(d.x, d.y) / PI_F * 0.5f + 0.5f;
+    float v = acosf(d.z) / PI_F;
+    float fw = (float)S.sky_w, fh = (float)S.sky_h;
+    float fx = rust_max(rust_min(u * fw, fw - 1.0f), 0.0f);
+    float fy = rust_max(rust_min(v * fh, fh - 1.0f), 0.0f);
+    uint32_t x = (uint32_t)fx, y = (uint32_t)fy;
+    uint32_t p = S.sky[(size_t)y * S.sky_w + x];
+    return mk((float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f, (float)((p >> 16) & 0xFFu) / 255.0f);
+}
+
+__device__ __forceinline__ f3 reflection(f3 n, f3 i) { return i - (2.0f * n) * dot(n, i); }  // material.rs:83-85
+__device__ __forceinline__ bool refraction(f3 normal, f3 i, float ior, f3& o) {             // material.rs:87-101
+    float side = dot(normal, i);
+    float cosi, eta;
+    f3 n;
+    if (side < 0.0f) { cosi = -side; eta = 1.0f / ior; n = normal; }
+    else { cosi = side; eta = ior; n = -normal; }
+    float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+    if (k > 0.0f) {
+        o = eta * i + (eta * cosi - sqrtf(k)) * n;
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ float fresnel(f3 normal, f3 i, float ior) {                      // material.rs:103-121
+    float side = dot(normal, i);
+    float cosi, etat, etai;
+    if (side < 0.0f) { cosi = -side; etat = ior; etai = 1.0f; }
+    else { cosi = side; etat = 1.0f; etai = ior; }
+    float sint = etai / etat * sqrtf(1.0f - cosi * cosi);
+    if (sint < 1.0f) {
+        float cost = sqrtf(1.0f - sint * sint);
+        float rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+        float rp = ((etat * cosi) - (etai * cost)) / ((etai * cosi) + (etat * cost));
+        return (rs * rs + rp * rp) / 2.0f;
+    }
+    return 1.0f;
+}
+__device__ __forceinline__ f3 material_diffuse(const DevMaterial& m) {  // Material::sample_at
+    if (m.kind == MAT_NULL) return mk(0.f, 1.f, 0.f);
+    if (m.kind == MAT_LAMBERT) return mk(m.color[0], m.color[1], m.color[2]);
+    if (m.kind == MAT_GLOSSY) return mk(m.color[0], m.color[1], m.color[2]) * (1.0f - m.p1);
+    return mk(0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ bool material_scatter(const DevMaterial& m, f3 n, f3 i, Rng& rng, f3& out_dir, f3& w) {
+    if (m.kind == MAT_METAL) {  // material.rs:32-35
+        out_dir = i - (2.0f * n) * dot(n, i);
+        w = fill(1.0f);
+        return true;
+    }
+    if (m.kind == MAT_GLOSSY) {  // material.rs:45-69 (accept test reads the mirror direction)
+        f3 out = reflection(n, i);
+        f3 a, b;
+        ortho_axes(out, a, b);
+        float side = dot(n, i) < 0.0f ? 1.0f : -1.0f;
+        for (int k = 0; k < 10; k++) {
+            float theta = rng_f32(rng) * 2.0f * PI_F;
+            float u = rng_f32(rng);
+            float p = powf(u, 2.0f / (1.0f + m.p0));
+            float r = sqrtf(1.0f - p);
+            float x = r * cosf(theta);
+            float y = r * sinf(theta);
+            float z = sqrtf(p);
+            f3 o = (x * a + y * b) + z * out;
+            if (dot(n, out) * side > 0.0f) {
+                out_dir = o;
+                w = fill(1.0f) * m.p1;
+                return true;
+            }
+        }
+        return false;
+    }
+    if (m.kind == MAT_TRANSPARENT) {  // material.rs:123-133
+        f3 o;
+        if (rng_f32(rng) < fresnel(n, i, m.p0)) {
+            o = reflection(n, i);
+        } else if (!refraction(n, i, m.p0, o)) {
+            return false;
+        }
+        out_dir = o;
+        w = fill(1.0f);
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ bool light_is_delta(const DevLight& l) {  // light.rs:29-31,76-78,125-127
+    if (l.kind == LIGHT_AMBIENT) return true;
+    if (l.kind == LIGHT_POINT) return l.param == 0.0f;
+    if (l.kind == LIGHT_DIRECTION) return l.param > 0.0f;
+    return false;
+}
+__device__ __forceinline__ void light_sample(const DevLight& l, f3 normal, Rng& rng, f3& dir, float& t_max, f3& ill) {
+    f3 E = mk(l.emission[0], l.emission[1], l.emission[2]);
+    if (l.kind == LIGHT_AMBIENT) {  // light.rs:24-27
+        dir = normal; t_max = 0.0f; ill = E;
+    } else if (l.kind == LIGHT_DIRECTION) {  // light.rs:97-123
+        f3 ld = mk(l.vec[0], l.vec[1], l.vec[2]);
+        f3 o;
+        if (l.param > 0.0f) {
+            float theta = rng_f32(rng) * 2.0f * PI_F;
+            float u = rng_f32(rng);
+            float p = powf(u, l.param);
+            float r = sqrtf(1.0f - p);
+            float x = r * cosf(theta);
+            float y = r * sinf(theta);
+            float z = sqrtf(p);
+            f3 a, b;
+            ortho_axes(ld, a, b);
+            o = (x * a + y * b) - z * ld;
+        } else {
+            o = -ld;
+        }
+        float c = rust_max(dot(o, normal), 0.0f);
+        dir = o; t_max = 1e12f; ill = E * c;
+    } else {  // LIGHT_AO, light.rs:144-158
+        float theta = rng_f32(rng) * 2.0f * PI_F;
+        float u = rng_f32(rng);
+        float r = sqrtf(u);
+        float x = r * cosf(theta);
+        float y = r * sinf(theta);
+        float z = sqrtf(1.0f - u);
+        f3 a, b;
+        ortho_axes(normal, a, b);
+        dir = (a * x + b * y) + normal * z;
+        t_max = l.param; ill = E;
+    }
+}
+
+// wave64 compaction: lanes with `take` get consecutive slots of a global queue; one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(bool take, uint32_t* counter) {
+    unsigned long long mask = __ballot(take);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t before = __popcll(mask & ((1ULL << lane) - 1ULL));
+    uint32_t total = __popcll(mask);
+    uint32_t base = 0;
+    int leader = mask ? (__ffsll((long long)mask) - 1) : 0;
+    if (take && (int)lane == leader) base = atomicAdd(counter, total);
+    base = __shfl(base, leader);
+    return base + before;
+}
+
+// Pixel slot -> pixel coordinates of the owned tile set (see rtamd_region).
+__device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, uint32_t& cx, uint32_t& cy) {
+    uint32_t per_tile = R.tile_w * R.tile_h;
+    uint32_t q = slot / per_tile, r = slot - q * per_tile;
+    uint32_t ty = r / R.tile_w, tx = r - ty * R.tile_w;
+    uint32_t tile = R.tile_first + q * R.tile_stride;
+    uint32_t tyi = tile / R.tiles_x, txi = tile - tyi * R.tiles_x;
+    uint32_t px = txi * R.tile_w + tx, py = tyi * R.tile_h + ty;
+    cx = R.x0 + px; cy = R.y0 + py;
+    return px < R.w && py < R.h && tile < R.n_tiles;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1: ray generation.  One lane per pixel slot of the chunk; sample (si, sj) of the regular
+// antialiasing grid (src/integrator.rs:33-48).  Also folds the previous sample's radiance into the
+// pixel sum (integrator.rs:50-53 adds the samples in generation order).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raygen(WaveBufs W, RegionDev R, CameraDev cam, uint32_t chunk_begin, uint32_t chunk_n,
+                                                uint32_t si, uint32_t sj, uint32_t aa, uint32_t first_sample) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = false;
+    uint32_t cx = 0, cy = 0;
+    if (i < chunk_n) valid = slot_pixel(R, chunk_begin + i, cx, cy);
+    f3 pos = mk(0, 0, 0), dir = mk(0, 0, 0);
+    if (valid) {
+        if (first_sample) {
+            uint64_t seed = (uint64_t)cx ^ __builtin_bswap64((uint64_t)cy);  // integrator.rs:36
+            Rng r = rng_seed(seed);
+            W.rng_lo[i] = r.lo; W.rng_hi[i] = r.hi;
+            W.sum[i] = 0.0f; W.sum[i + W.cap] = 0.0f; W.sum[i + 2 * W.cap] = 0.0f;
+        } else {
+            W.sum[i] = W.sum[i] + W.L[i];
+            W.sum[i + W.cap] = W.sum[i + W.cap] + W.L[i + W.cap];
+            W.sum[i + 2 * W.cap] = W.sum[i + 2 * W.cap] + W.L[i + 2 * W.cap];
+        }
+        W.L[i] = 0.0f; W.L[i + W.cap] = 0.0f; W.L[i + 2 * W.cap] = 0.0f;
+        W.beta[i] = 1.0f; W.beta[i + W.cap] = 1.0f; W.beta[i + 2 * W.cap] = 1.0f;
+        float n = (float)aa;
+        float x = (float)cx + ((float)si + 0.5f) / n - 0.5f;  // integrator.rs:41-42
+        float y = (float)cy + ((float)sj + 0.5f) / n - 0.5f;
+        float u = 2.0f * (x / (float)cam.width) - 1.0f;       // scene.rs:84-90
+        float v = 2.0f * (y / (float)cam.height) - 1.0f;
+        f3 d = (cam.dir + u * cam.horizontal) + v * cam.vertical;
+        dir = normalize(d);
+        pos = cam.pos;
+    }
+    uint32_t q = wave_append(valid, &W.counts[0]);
+    if (valid) {
+        W.q_slot[0][q] = i;
+        float* r = W.q_ray[0];
+        r[q] = pos.x; r[q + W.cap] = pos.y; r[q + 2 * W.cap] = pos.z;
+        r[q + 3 * W.cap] = dir.x; r[q + 4 * W.cap] = dir.y; r[q + 5 * W.cap] = dir.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2: closest-hit trace of the current queue (scene.root.hit(ray, 1e12), integrator.rs:64)
+// and reconstruction of the HitResult the shading stage needs.
+// ------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur) {
+    LdsMem mem;
+    const LdsMem* lm = stage_mesh<USE_LDS>(S, mem);
+    const uint32_t n = W.counts[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        W.counts[cur ^ 1] = 0;   // next queue
+        W.counts[2] = 0;         // lit queue
+        W.stats[0] += n;         // closest-hit rays
+    }
+    const float* r = W.q_ray[cur];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        f3 pos = mk(r[i], r[i + W.cap], r[i + 2 * W.cap]);
+        f3 dir = mk(r[i + 3 * W.cap], r[i + 4 * W.cap], r[i + 5 * W.cap]);
+        Best b;
+        b.obj = MISS; b.prim = 0; b.t_local = 0.f; b.u = 0.f; b.v = 0.f;
+        float t_hit;
+        bool found = scene_closest(S, lm, pos, dir, 1e12f, b, t_hit);
+        if (found) {
+            f3 hp, hn;
+            float hu, hv;
+            reconstruct_hit(S, b, pos, dir, hp, hn, hu, hv);
+            W.h_mat[i] = S.objects[b.obj].material;
+            W.h_f[i] = hu; W.h_f[i + W.cap] = hv;
+            W.h_f[i + 2 * W.cap] = hp.x; W.h_f[i + 3 * W.cap] = hp.y; W.h_f[i + 4 * W.cap] = hp.z;
+            W.h_f[i + 5 * W.cap] = hn.x; W.h_f[i + 6 * W.cap] = hn.y; W.h_f[i + 7 * W.cap] = hn.z;
+        } else {
+            W.h_mat[i] = MISS;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 3: shade (integrate_recur after the hit, src/integrator.rs:66-102 with scatter_rays = 1).
+// Miss -> skybox, path ends.  Hit -> diffuse colour; if non-black, draw the light samples in light
+// order (their shadow rays go to the lit queue), then draw the scatter direction and append the
+// continuation ray to the next queue.  The per-pixel random stream is consumed in exactly the
+// order of the reference's recursion.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint32_t cur, int32_t depth, int32_t max_depth, int32_t shadow_rays) {
+    const uint32_t n = W.counts[cur];
+    const float* r = W.q_ray[cur];
+    const uint32_t cap = W.cap;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_iter = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < n_iter; it++) {
+        // ---- phase A: load the path, classify (miss / lit / unlit) ----
+        uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = i < n;
+        bool hit = false, lit = false, cont = false;
+        uint32_t slot = 0, mat = MISS;
+        f3 dir = mk(0, 0, 0), p = mk(0, 0, 0), p_out = mk(0, 0, 0), p_in = mk(0, 0, 0), nrm = mk(0, 0, 0);
+        f3 diffuse = mk(0, 0, 0), beta = mk(1, 1, 1);
+        if (active) {
+            slot = W.q_slot[cur][i];
+            dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
+            beta = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
+            mat = W.h_mat[i];
+            if (mat == MISS) {  // integrator.rs:66
+                f3 c = beta * sky_color(S, dir);
+                W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
+            } else {
+                hit = true;
+                f3 hp = mk(W.h_f[i + 2 * cap], W.h_f[i + 3 * cap], W.h_f[i + 4 * cap]);
+                f3 hn = mk(W.h_f[i + 5 * cap], W.h_f[i + 6 * cap], W.h_f[i + 7 * cap]);
+                nrm = normalize(hn);                                  // integrator.rs:72-76
+                bool outside = dot(nrm, -dir) > 0.0f;
+                p_out = hp + nrm * 0.001f;
+                p_in = hp - nrm * 0.001f;
+                p = outside ? p_out : p_in;
+                diffuse = material_diffuse(S.materials[mat]);
+                lit = !is_zero(diffuse);                               // integrator.rs:80
+            }
+        }
+        uint32_t lq = wave_append(lit, &W.counts[2]);
+        // ---- phase B: draw light samples, then the scatter direction (same stream order) ----
+        f3 next_pos = mk(0, 0, 0), next_dir = mk(0, 0, 0);
+        if (hit) {
+            Rng rng;
+            rng.lo = W.rng_lo[slot]; rng.hi = W.rng_hi[slot];
+            const DevMaterial m = S.materials[mat];
+            if (lit) {                                                 // integrator.rs:80-88
+                W.lit_slot[lq] = slot;
+                float* f = W.lit_f;
+                f[lq] = p.x; f[lq + cap] = p.y; f[lq + 2 * cap] = p.z;
+                f[lq + 3 * cap] = beta.x; f[lq + 4 * cap] = beta.y; f[lq + 5 * cap] = beta.z;
+                f[lq + 6 * cap] = diffuse.x; f[lq + 7 * cap] = diffuse.y; f[lq + 8 * cap] = diffuse.z;
+                uint32_t s = 0;
+                for (uint32_t l = 0; l < S.n_lights; l++) {
+                    const DevLight lt = S.lights[l];
+                    int ns = light_is_delta(lt) ? 1 : shadow_rays;
+                    for (int k = 0; k < ns; k++, s++) {
+                        f3 sd, ill; float tm;
+                        light_sample(lt, nrm, rng, sd, tm, ill);
+                        float* q = W.smp + (size_t)s * 7 * cap + lq;
+                        q[0] = sd.x; q[cap] = sd.y; q[2 * (size_t)cap] = sd.z; q[3 * (size_t)cap] = tm;
+                        q[4 * (size_t)cap] = ill.x; q[5 * (size_t)cap] = ill.y; q[6 * (size_t)cap] = ill.z;
+                    }
+                }
+            }
+            f3 out, w;
+            if (material_scatter(m, nrm, dir, rng, out, w)) {          // integrator.rs:90-101
+                f3 p2 = dot(out, nrm) > 0.0f ? p_out : p_in;
+                f3 nb = beta * w;
+                if (depth + 1 >= max_depth) {                          // integrator.rs:59-61 at depth+1
+                    f3 c = nb * sky_color(S, out);
+                    W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
+                } else {
+                    cont = true;
+                    next_pos = p2; next_dir = out;
+                    W.beta[slot] = nb.x; W.beta[slot + cap] = nb.y; W.beta[slot + 2 * cap] = nb.z;
+                }
+            }
+            W.rng_lo[slot] = rng.lo; W.rng_hi[slot] = rng.hi;
+        }
+        // ---- compaction of the continuing paths into the next ray queue ----
+        uint32_t nq = wave_append(cont, &W.counts[cur ^ 1]);
+        if (cont) {
+            W.q_slot[cur ^ 1][nq] = slot;
+            float* o = W.q_ray[cur ^ 1];
+            o[nq] = next_pos.x; o[nq + cap] = next_pos.y; o[nq + 2 * cap] = next_pos.z;
+            o[nq + 3 * cap] = next_dir.x; o[nq + 4 * cap] = next_dir.y; o[nq + 5 * cap] = next_dir.z;
+        }
+    }
+}
+
+// Marks every queued path as a miss (max_depth = 0: integrate_recur returns the skybox at once).
+__global__ void k_mark_miss(WaveBufs W) {
+    const uint32_t n = W.counts[0];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W.h_mat[i] = MISS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 4: shadow rays of the lit queue (illumination(), src/integrator.rs:107-132) and the
+// `color += diffuse * illumination` of integrator.rs:87, weighted by the path throughput.
+// ------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_wave_shadow(DevScene S, WaveBufs W, int32_t shadow_rays) {
+    LdsMem mem;
+    const LdsMem* lm = stage_mesh<USE_LDS>(S, mem);
+    const uint32_t n = W.counts[2];
+    const uint32_t cap = W.cap;
+    uint32_t traced = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float* f = W.lit_f;
+        f3 p = mk(f[j], f[j + cap], f[j + 2 * cap]);
+        f3 beta = mk(f[j + 3 * cap], f[j + 4 * cap], f[j + 5 * cap]);
+        f3 diffuse = mk(f[j + 6 * cap], f[j + 7 * cap], f[j + 8 * cap]);
+        f3 illum = fill(0.0f);
+        uint32_t s = 0;
+        for (uint32_t l = 0; l < S.n_lights; l++) {
+            const DevLight lt = S.lights[l];
+            int ns = light_is_delta(lt) ? 1 : shadow_rays;
+            f3 total = fill(0.0f);
+            for (int k = 0; k < ns; k++, s++) {
+                const float* q = W.smp + (size_t)s * 7 * cap + j;
+                f3 sd = mk(q[0], q[cap], q[2 * (size_t)cap]);
+                float tm = q[3 * (size_t)cap];
+                f3 ill = mk(q[4 * (size_t)cap], q[5 * (size_t)cap], q[6 * (size_t)cap]);
+                bool visible = true;
+                if (!(tm == 0.0f)) {                       // integrator.rs:124
+                    traced++;
+                    visible = !scene_any(S, lm, p, sd, tm);
+                }
+                if (visible) total = total + ill;
+            }
+            illum = illum + total / (float)ns;             // integrator.rs:131, :84
+        }
+        f3 c = beta * (diffuse * illum);
+        uint32_t slot = W.lit_slot[j];
+        W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
+    }
+    // any-hit ray count: wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
+    if ((threadIdx.x & 63u) == 0 && traced) atomicAdd((unsigned long long*)&W.stats[1], (unsigned long long)traced);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 5: pixel = mean of the samples (integrator.rs:50-53), written to the tile-major output.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(WaveBufs W, RegionDev R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunk_n) return;
+    uint32_t cx, cy;
+    bool valid = slot_pixel(R, chunk_begin + i, cx, cy);
+    size_t o = 3 * (size_t)(chunk_begin + i);
+    if (valid) {
+        out[o] = (W.sum[i] + W.L[i]) / n_samples;
+        out[o + 1] = (W.sum[i + W.cap] + W.L[i + W.cap]) / n_samples;
+        out[o + 2] = (W.sum[i + 2 * W.cap] + W.L[i + 2 * W.cap]) / n_samples;
+    } else {
+        out[o] = 0.0f; out[o + 1] = 0.0f; out[o + 2] = 0.0f;
+    }
+}
+
+__global__ void k_quantize(const float* rgb, size_t n, uint8_t* out) {  // src/render.rs:62-72
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float f = floorf(rgb[i] * 256.0f);
+    f = rust_min(rust_max(f, 0.0f), 255.0f);
+    out[i] = (uint8_t)f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t trace_grid(const LaunchCfg& cfg, size_t n) {
+    size_t need = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    size_t cap = (size_t)cfg.num_cus * cfg.trace_blocks_per_cu;
+    size_t g = need < cap ? need : cap;
+    return (uint32_t)(g ? g : 1);
+}
+
+hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint32_t g = trace_grid(cfg, n);
+    if (cfg.use_lds && S.lds_mesh != MISS)
+        hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, rays, out, (uint32_t)n);
+    else
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, rays, out, (uint32_t)n);
+    return hipGetLastError();
+}
+hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, uint8_t* out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint32_t g = trace_grid(cfg, n);
+    if (cfg.use_lds && S.lds_mesh != MISS)
+        hipLaunchKernelGGL(k_trace_any<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, rays, out, (uint32_t)n);
+    else
+        hipLaunchKernelGGL(k_trace_any<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, rays, out, (uint32_t)n);
+    return hipGetLastError();
+}
+hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
+                         uint32_t si, uint32_t sj, uint32_t aa, bool first, hipStream_t st) {
+    uint32_t g = (chunk_n + 255) / 256;
+    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(256), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, first ? 1u : 0u);
+    return hipGetLastError();
+}
+hipError_t launch_mark_miss(const WaveBufs& W, size_t upper, hipStream_t st) {
+    uint32_t g = (uint32_t)((upper + 255) / 256);
+    if (g > 2048) g = 2048;
+    if (!g) g = 1;
+    hipLaunchKernelGGL(k_mark_miss, dim3(g), dim3(256), 0, st, W);
+    return hipGetLastError();
+}
+hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, size_t upper, hipStream_t st) {
+    uint32_t g = trace_grid(cfg, upper);
+    if (cfg.use_lds && S.lds_mesh != MISS)
+        hipLaunchKernelGGL(k_wave_trace<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, W, cur);
+    else
+        hipLaunchKernelGGL(k_wave_trace<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, W, cur);
+    return hipGetLastError();
+}
+hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
+                             int shadow_rays, size_t upper, hipStream_t st) {
+    size_t need = (upper + 255) / 256;
+    size_t capg = (size_t)cfg.num_cus * 8;
+    uint32_t g = (uint32_t)(need < capg ? need : capg);
+    if (!g) g = 1;
+    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(256), 0, st, S, W, cur, depth, max_depth, shadow_rays);
+    return hipGetLastError();
+}
+hipError_t launch_wave_shadow(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, size_t upper, hipStream_t st) {
+    uint32_t g = trace_grid(cfg, upper);
+    if (cfg.use_lds && S.lds_mesh != MISS)
+        hipLaunchKernelGGL(k_wave_shadow<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, W, shadow_rays);
+    else
+        hipLaunchKernelGGL(k_wave_shadow<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, W, shadow_rays);
+    return hipGetLastError();
+}
+hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out, hipStream_t st) {
+    uint32_t g = (chunk_n + 255) / 256;
+    hipLaunchKernelGGL(k_finalize, dim3(g), dim3(256), 0, st, W, R, chunk_begin, chunk_n, n_samples, out);
+    return hipGetLastError();
+}
+hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint32_t g = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(k_quantize, dim3(g), dim3(256), 0, st, rgb, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace rtamd

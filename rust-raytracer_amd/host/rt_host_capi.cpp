@@ -1,0 +1,134 @@
+// C facade over the host library so that Python (ctypes) can drive it: build one of the scene
+// scripts, upload it to a GPU context, inspect its flattened arrays, trace and render.
+#include <cstdio>
+#include <cstring>
+
+#include "rt_host.hpp"
+
+using namespace rth;
+
+namespace {
+struct Handle {
+    Scene scene;
+    std::unique_ptr<Device> dev;
+    std::string error;
+};
+thread_local std::string g_error;
+std::shared_ptr<const Image> sky_from(const uint8_t* rgb, int w, int h) {
+    if (rgb && w > 0 && h > 0) return Image::from_rgb(rgb, (uint32_t)w, (uint32_t)h);
+    return nullptr;
+}
+template <class F>
+void* guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        std::fprintf(stderr, "rth: %s\n", e.what());
+        return nullptr;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* rth_last_error() { return g_error.c_str(); }
+
+void* rth_scene_main(const char* ply, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
+    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_main(ply, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
+}
+void* rth_scene_spheres(int n, uint64_t seed, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
+    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_spheres(n, seed, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
+}
+void* rth_scene_grid(const char* ply, int nx, int ny, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
+    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
+}
+void rth_scene_free(void* p) { delete (Handle*)p; }
+
+// Camera::new(w, h).position(pos).look_towards(dir, up) at another resolution, keeping the pose:
+// re-derives the image-plane vectors exactly like the builder does (scene.rs:35-78).
+void rth_scene_set_camera_size(void* p, int w, int h, const float pos[3], const float lookat[3], const float up[3]) {
+    Handle* hd = (Handle*)p;
+    Camera cam((size_t)w, (size_t)h);
+    cam.position(Vec3D(pos[0], pos[1], pos[2])).look_at(Vec3D(lookat[0], lookat[1], lookat[2]), Vec3D(up[0], up[1], up[2]));
+    hd->scene.camera = cam;
+}
+void rth_scene_camera(void* p, rtamd_camera* out) { *out = ((Handle*)p)->scene.camera.flat(); }
+
+// Opens the GPU (once) and uploads the flattened scene.  Returns the rtamd context or NULL.
+void* rth_scene_upload(void* p, int device_id) {
+    Handle* h = (Handle*)p;
+    return guarded([&]() -> void* {
+        if (!h->dev) h->dev.reset(new Device(device_id));
+        h->scene.upload(*h->dev);
+        return h->dev->ctx;
+    });
+}
+
+// Host-side flattening without a GPU: fills the flat arrays so that tests can compare tree shape with
+// the CPU oracle.  which: 0 = first mesh tree, 1 = first object tree.
+int rth_scene_tree_size(void* p, int which, uint32_t out[2]) {
+    Handle* h = (Handle*)p;
+    const BvhTree* t = nullptr;
+    for (const auto& it : h->scene.root.items) {
+        if (which == 1 && it.is_tree) { t = &it.tree->tree; break; }
+    }
+    if (which == 0) {
+        // find the first mesh by flattening into a scratch FlatScene
+        FlatScene fs;
+        std::vector<rtamd_xform_op> ops;
+        for (const auto& it : h->scene.root.items) {
+            if (it.is_tree) { for (const auto& o : it.tree->objs) { o.geometry->flatten(fs, ops, 0); if (!fs.mesh_refs.empty()) break; } }
+            else it.object.geometry->flatten(fs, ops, 0);
+            if (!fs.mesh_refs.empty()) break;
+        }
+        if (fs.mesh_refs.empty()) return -1;
+        out[0] = (uint32_t)fs.mesh_refs[0]->tree.nodes.size();
+        out[1] = (uint32_t)fs.mesh_refs[0]->tree.order.size();
+        return 0;
+    }
+    if (!t) return -1;
+    out[0] = (uint32_t)t->nodes.size(); out[1] = (uint32_t)t->order.size();
+    return 0;
+}
+int rth_scene_tree_dump(void* p, int which, uint32_t* nodes8, uint32_t* order, uint32_t stats[5]) {
+    Handle* h = (Handle*)p;
+    const BvhTree* t = nullptr;
+    std::shared_ptr<const Mesh> keep;
+    if (which == 1) {
+        for (const auto& it : h->scene.root.items) if (it.is_tree) { t = &it.tree->tree; break; }
+    } else {
+        FlatScene fs;
+        std::vector<rtamd_xform_op> ops;
+        for (const auto& it : h->scene.root.items) {
+            if (it.is_tree) { for (const auto& o : it.tree->objs) { o.geometry->flatten(fs, ops, 0); if (!fs.mesh_refs.empty()) break; } }
+            else it.object.geometry->flatten(fs, ops, 0);
+            if (!fs.mesh_refs.empty()) break;
+        }
+        if (!fs.mesh_refs.empty()) { keep = fs.mesh_refs[0]; t = &keep->tree; }
+    }
+    if (!t) return -1;
+    static_assert(sizeof(rtamd_bvh_node) == 32, "node layout");
+    std::memcpy(nodes8, t->nodes.data(), t->nodes.size() * 32);
+    std::memcpy(order, t->order.data(), t->order.size() * 4);
+    bvh_statistics(*t, stats);
+    return 0;
+}
+
+// render::parallel_render on the uploaded scene; out = width*height*3 floats.
+int rth_render(void* p, const int params[4], float* out, rtamd_stats* stats) {
+    Handle* h = (Handle*)p;
+    if (!h->dev) { g_error = "scene not uploaded"; return -1; }
+    try {
+        WhittedIntegrator ig;
+        ig.max_depth = params[0]; ig.shadow_rays = params[1]; ig.scatter_rays = params[2]; ig.antialiasing = params[3];
+        std::vector<float> buf = render::parallel_render(*h->dev, h->scene, ig, stats, true);
+        std::memcpy(out, buf.data(), buf.size() * 4);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+}  // extern "C"

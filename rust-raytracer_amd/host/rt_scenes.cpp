@@ -1,0 +1,111 @@
+// Scene scripts: the reference's hard-coded scene (src/main.rs:22-83) and the two synthetic scenes
+// used for the larger benchmark configurations.
+#include "rt_host.hpp"
+
+namespace rth {
+
+static std::vector<Light> main_lights() {  // main.rs:67-76
+    return {AmbientLight(Vec3D::one(), 0.1f),
+            DirectionLight(vec3d(-2.5f, -3.0f, -3.0f), 0.01f, COLOR_WHITE, 0.4f),
+            AmbientOcclusion(1e12f, Vec3D::one(), 0.5f)};
+}
+
+Scene scene_main(const std::string& ply_path, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h) {
+    std::vector<Object> list;
+    auto mesh = loader::load_ply_as_mesh(ply_path);
+    GeomPtr tmesh = Transform::make(mesh)->scale(20.0f)->rotate_x(to_radians(90.0f));  // main.rs:25-27
+
+    AABB bb = tmesh->bounding_box();
+    GeomPtr cube = Cuboid::make(vec3d(-5.0f, -5.0f, bb.min.z), vec3d(5.0f, 5.0f, bb.min.z - 1.0f));
+    Vec3D c = (bb.min + bb.max) / 2.0f;
+
+    list.push_back(Object::with_material(tmesh, Transparent(1.0f / 0.6f)));
+    list.push_back(Object::with_material(Translate::make(tmesh)->translate_y(-2.5f), Metal()));
+    list.push_back(Object::with_material(Translate::make(tmesh)->translate_y(2.5f), Lambartian(COLOR_WHITE)));
+    list.push_back(Object::with_material(cube, Glossy(1e3f, 0.3f, COLOR_WHITE)));
+
+    Vec3D pos(-6.0f, -6.0f, 3.0f);
+    Vec3D up = -Vec3D::z_axis();
+    Vec3D focus = c + Vec3D(0.0f, 0.0f, 0.1f);
+    Camera cam(cam_w, cam_h);
+    cam.position(pos).look_at(focus, up);
+
+    Scene scene;
+    scene.root = GeometryList::from_vec(list);
+    scene.camera = cam;
+    scene.skybox = skybox;
+    scene.lights = main_lights();
+    return scene;
+}
+
+// splitmix64 -> uniform float in [0,1): (z >> 40) * 2^-24.
+namespace {
+struct SplitMix64 {
+    uint64_t s;
+    uint64_t next() {
+        s += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    float uniform() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
+};
+}  // namespace
+
+// n spheres, each its own Object (even index: white Lambertian, odd: Metal), in one AABBTree<Object>
+// with hit_cost 1.0, above a glossy floor cuboid.  Centres uniform in [-12,12]^2 x [0.3,4.0], radii
+// uniform in [0.08,0.25]; per sphere the generator is drawn in the order cx, cy, cz, r.
+Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h) {
+    SplitMix64 g{seed};
+    std::vector<Object> objs;
+    objs.reserve((size_t)n);
+    for (int i = 0; i < n; i++) {
+        float cx = -12.0f + 24.0f * g.uniform();
+        float cy = -12.0f + 24.0f * g.uniform();
+        float cz = 0.3f + 3.7f * g.uniform();
+        float r = 0.08f + 0.17f * g.uniform();
+        objs.push_back(Object::with_material(Sphere(Vec3D(cx, cy, cz), r), (i % 2 == 0) ? Lambartian(COLOR_WHITE) : Metal()));
+    }
+    Scene scene;
+    scene.root.push(ObjectTree::make(std::move(objs), 1.0f));
+    scene.root.push(Object::with_material(Cuboid::make(vec3d(-15.0f, -15.0f, 0.0f), vec3d(15.0f, 15.0f, -1.0f)), Glossy(1e3f, 0.3f, COLOR_WHITE)));
+    Camera cam(cam_w, cam_h);
+    cam.position(Vec3D(-18.0f, -18.0f, 9.0f)).look_at(Vec3D(0.0f, 0.0f, 1.0f), -Vec3D::z_axis());
+    scene.camera = cam;
+    scene.skybox = skybox;
+    scene.lights = main_lights();
+    return scene;
+}
+
+// nx * ny instances of the scaled + rotated mesh on a grid of pitch 4.0 (row-major, x fastest),
+// materials cycling Transparent / Metal / Lambertian by (ix + iy) % 3, in one AABBTree<Object> with
+// hit_cost 1.0, above a glossy floor cuboid.
+Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h) {
+    auto mesh = loader::load_ply_as_mesh(ply_path);
+    GeomPtr tmesh = Transform::make(mesh)->scale(20.0f)->rotate_x(to_radians(90.0f));
+    AABB bb = tmesh->bounding_box();
+    const float pitch = 4.0f;
+    float x0 = -0.5f * pitch * (float)(nx - 1), y0 = -0.5f * pitch * (float)(ny - 1);
+    std::vector<Object> objs;
+    objs.reserve((size_t)nx * ny);
+    for (int iy = 0; iy < ny; iy++)
+        for (int ix = 0; ix < nx; ix++) {
+            Vec3D off(x0 + pitch * (float)ix, y0 + pitch * (float)iy, 0.0f);
+            Material m = ((ix + iy) % 3 == 0) ? Transparent(1.0f / 0.6f) : (((ix + iy) % 3 == 1) ? Metal() : Lambartian(COLOR_WHITE));
+            objs.push_back(Object::with_material(Translate::make(tmesh)->translate(off), m));
+        }
+    float hx = 0.5f * pitch * (float)nx + 2.0f, hy = 0.5f * pitch * (float)ny + 2.0f;
+    Scene scene;
+    scene.root.push(ObjectTree::make(std::move(objs), 1.0f));
+    scene.root.push(Object::with_material(Cuboid::make(vec3d(-hx, -hy, bb.min.z), vec3d(hx, hy, bb.min.z - 1.0f)), Glossy(1e3f, 0.3f, COLOR_WHITE)));
+    float ext = hx > hy ? hx : hy;
+    Camera cam(cam_w, cam_h);
+    cam.position(Vec3D(-1.2f * ext, -1.2f * ext, 0.9f * ext)).look_at(Vec3D(0.0f, 0.0f, 0.0f), -Vec3D::z_axis());
+    scene.camera = cam;
+    scene.skybox = skybox;
+    scene.lights = main_lights();
+    return scene;
+}
+
+}  // namespace rth

@@ -1,0 +1,157 @@
+"""GPU parity of the batched Geometry::hit / is_hit entry points against the CPU oracle.
+
+Bar: object id, primitive id (tree order), t, u, v bit-exact for triangle meshes and cuboids; for
+spheres obj / t bit-exact and u, v (atan2 / acos, library-dependent last bits) within 1e-6 absolute.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def random_rays(n, seed, center=(0.0, 0.0, 1.0), radius=9.0, tmax=1e12):
+    """Seeded incoherent rays: origins in a ball around the scene, directions uniform on the sphere."""
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(3, n))
+    o = o / np.linalg.norm(o, axis=0) * (rng.random(n) ** (1 / 3)) * radius + np.array(center)[:, None]
+    d = rng.normal(size=(3, n))
+    d = d / np.linalg.norm(d, axis=0)
+    rays = np.empty((7, n), np.float32)
+    rays[0:3] = o
+    rays[3:6] = d.astype(np.float32)
+    # the oracle's sphere test assumes unit directions like the reference; renormalise in f32
+    dn = np.sqrt((rays[3:6].astype(np.float64) ** 2).sum(axis=0))
+    rays[3:6] = (rays[3:6] / dn).astype(np.float32)
+    rays[6] = tmax
+    return np.ascontiguousarray(rays)
+
+
+def check_closest(rt, got, ref, exact_uv=True):
+    ref_obj = ref["obj"].astype(np.int64)
+    ref_obj[ref_obj < 0] = rt.MISS
+    assert np.array_equal(got["obj"].astype(np.int64), ref_obj)
+    hit = ref["obj"] >= 0
+    assert np.array_equal(got["prim"][hit], ref["prim"][hit])
+    assert np.array_equal(got["t"][hit].view(np.uint32), ref["t"][hit].view(np.uint32))
+    if exact_uv:
+        assert np.array_equal(got["u"][hit].view(np.uint32), ref["u"][hit].view(np.uint32))
+        assert np.array_equal(got["v"][hit].view(np.uint32), ref["v"][hit].view(np.uint32))
+    else:
+        assert np.allclose(got["u"][hit], ref["u"][hit], atol=1e-6, rtol=0)
+        assert np.allclose(got["v"][hit], ref["v"][hit], atol=1e-6, rtol=0)
+    assert np.all(got["prim"][~hit] == rt.MISS)
+    return int(hit.sum())
+
+
+@pytest.fixture(scope="module")
+def main_pair(rt, ol, sky):
+    cam = (480, 270)
+    return rt.Scene.main(sky=sky, cam=cam).upload(0), ol.OracleScene.main(sky=sky, cam=cam), cam
+
+
+def test_primary_rays_bit_exact(rt, main_pair):
+    gpu, cpu, cam = main_pair
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 0.3 * rays.shape[1]
+
+
+def test_incoherent_rays_bit_exact(rt, main_pair):
+    gpu, cpu, _ = main_pair
+    rays = random_rays(200_000, seed=7)
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 1000
+
+
+def test_any_hit_matches(rt, main_pair):
+    gpu, cpu, _ = main_pair
+    rays = random_rays(200_000, seed=11)
+    rays[6] = np.random.default_rng(3).uniform(0.0, 12.0, rays.shape[1]).astype(np.float32)
+    got = gpu.trace_any(rays)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(got, ref)
+    assert 0 < ref.sum() < ref.size
+
+
+def test_lds_and_global_paths_agree(rt, main_pair):
+    gpu, cpu, _ = main_pair
+    rays = random_rays(100_000, seed=13)
+    gpu.set_option(rt.OPT_LDS_SCENE, 0)
+    a = gpu.trace_closest(rays)
+    sa = gpu.trace_any(rays)
+    gpu.set_option(rt.OPT_LDS_SCENE, 1)
+    b = gpu.trace_closest(rays)
+    sb = gpu.trace_any(rays)
+    for k in ("obj", "prim", "t", "u", "v"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert np.array_equal(sa, sb)
+    check_closest(rt, a, cpu.trace_closest(rays))
+
+
+def test_axis_aligned_and_degenerate_rays(rt, main_pair):
+    """Rays with zero direction components (inf / NaN slabs), origins on box planes, tiny t_max."""
+    gpu, cpu, _ = main_pair
+    nodes, _, _ = cpu.bvh(0)
+    rng = np.random.default_rng(5)
+    n = 30_000
+    rays = random_rays(n, seed=17)
+    axis = rng.integers(0, 3, n)
+    for a in range(3):  # axis-aligned directions
+        sel = (axis == a) & (np.arange(n) % 2 == 0)
+        rays[3:6, sel] = 0.0
+        rays[3 + a, sel] = np.where(rng.random(sel.sum()) < 0.5, 1.0, -1.0)
+    rays[3, ::7] = -0.0  # negative zero component
+    rays[6, ::5] = rng.uniform(0, 1e-3, rays[6, ::5].shape)  # tiny t_max
+    rays[6, 1::11] = 0.0
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+
+
+def test_empty_and_ragged_batches(rt, main_pair):
+    gpu, cpu, _ = main_pair
+    empty = np.zeros((7, 0), np.float32)
+    assert gpu.trace_closest(empty)["obj"].size == 0
+    assert gpu.trace_any(empty).size == 0
+    for n in (1, 63, 65, 511, 513, 4097):
+        rays = random_rays(n, seed=100 + n)
+        check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+
+
+def test_sphere_scene(rt, ol, sky):
+    cam = (320, 240)
+    gpu = rt.Scene.spheres(n=3000, seed=1, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.spheres(n=3000, seed=1, sky=sky, cam=cam)
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays), exact_uv=False)
+    assert hits > 0.5 * rays.shape[1]
+    rays = random_rays(100_000, seed=23, center=(0, 0, 2), radius=14.0)
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays), exact_uv=False)
+    rays[6] = np.random.default_rng(4).uniform(0.0, 20.0, rays.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+
+
+def test_instanced_grid_scene(rt, ol, sky):
+    cam = (320, 240)
+    gpu = rt.Scene.grid(6, 5, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.grid(6, 5, sky=sky, cam=cam)
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 0.3 * rays.shape[1]
+    rays = random_rays(100_000, seed=29, center=(0, 0, 1), radius=16.0)
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    rays[6] = np.random.default_rng(6).uniform(0.0, 20.0, rays.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+
+
+def test_errors_are_reported_not_fatal(rt, sky):
+    s = rt.Scene.main(sky=sky, cam=(64, 64))
+    with pytest.raises(rt.RtamdError):
+        s.trace_closest(np.zeros((7, 4), np.float32))  # not uploaded
+    s.upload(0)
+    with pytest.raises(rt.RtamdError):
+        s.render(scatter_rays=2)  # unsupported on the device: error code, no abort
+    with pytest.raises(rt.RtamdError):
+        s.render(region=rt.Scene.make_region(64, 64, rect=(0, 0, 128, 64)))  # outside the camera image
