@@ -37,8 +37,12 @@ def check_closest(rt, got, ref, exact_uv=True):
         assert np.array_equal(got["u"][hit].view(np.uint32), ref["u"][hit].view(np.uint32))
         assert np.array_equal(got["v"][hit].view(np.uint32), ref["v"][hit].view(np.uint32))
     else:
-        assert np.allclose(got["u"][hit], ref["u"][hit], atol=1e-6, rtol=0)
-        assert np.allclose(got["v"][hit], ref["v"][hit], atol=1e-6, rtol=0)
+        # acos of a normal component that rounds above 1 is NaN on both sides
+        for k in ("u", "v"):
+            g, r = got[k][hit], ref[k][hit]
+            assert np.array_equal(np.isnan(g), np.isnan(r)), k
+            ok = ~np.isnan(r)
+            assert np.abs(g[ok] - r[ok]).max(initial=0.0) <= 1e-6, (k, float(np.abs(g[ok] - r[ok]).max()))
     assert np.all(got["prim"][~hit] == rt.MISS)
     return int(hit.sum())
 
