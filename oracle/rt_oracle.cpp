@@ -314,7 +314,7 @@ void moller_trumbore(V3 a, V3 b, V3 c, const Ray& ray, float out[3]) {
 }
 bool Triangle::hit(const Ray& ray, float t_max, HitResult& h) const {  // triangle.rs:41-57
     float r[3];
-    g_cnt.tris_tested++;
+    g_cnt.tri();
     moller_trumbore(a, b, c, ray, r);
     float t = r[0], u = r[1], v = r[2];
     if (t >= 0.0f && t <= t_max && u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
@@ -329,7 +329,7 @@ bool Triangle::hit(const Ray& ray, float t_max, HitResult& h) const {  // triang
 }
 bool Triangle::is_hit(const Ray& ray, float t_max) const {  // triangle.rs:59-62
     float r[3];
-    g_cnt.tris_tested++;
+    g_cnt.tri();
     moller_trumbore(a, b, c, ray, r);
     return r[0] >= 0.0f && r[0] <= t_max && r[1] >= 0.0f && r[2] >= 0.0f && r[1] + r[2] <= 1.0f;
 }
@@ -343,7 +343,7 @@ bool MeshTriangle::hit(const Ray& ray, float t_max, HitResult& h) const {  // me
     const std::vector<V3>& d = data->data;
     V3 a = d[v[0]], b = d[v[1]], c = d[v[2]];
     float r[3];
-    g_cnt.tris_tested++;
+    g_cnt.tri();
     moller_trumbore(a, b, c, ray, r);
     float t = r[0], u = r[1], w = r[2];
     if (t >= 0.0f && t <= t_max && u >= 0.0f && w >= 0.0f && u + w <= 1.0f) {
@@ -531,7 +531,7 @@ bool AABBTree<T>::hit(const Ray& ray, float t_max, HitResult& result) const {
     bool neg[3] = {std::signbit(inv[0]), std::signbit(inv[1]), std::signbit(inv[2])};
     while (i < n) {
         const BvhNode& node = nodes[i];
-        g_cnt.nodes_visited++;
+        g_cnt.node();
         float t0, t1;
         if (node.bb.fast_intersect_ray(ray.pos, inv, neg, t0, t1)) {
             if (t0 <= t_max + 0.01f && t1 >= -0.01f) {
@@ -563,7 +563,7 @@ bool AABBTree<T>::is_hit(const Ray& ray, float t_max) const {
     bool neg[3] = {std::signbit(inv[0]), std::signbit(inv[1]), std::signbit(inv[2])};
     while (i < n) {
         const BvhNode& node = nodes[i];
-        g_cnt.nodes_visited++;
+        g_cnt.node();
         float t0, t1;
         if (node.bb.fast_intersect_ray(ray.pos, inv, neg, t0, t1)) {
             if (t0 <= t_max + 0.01f && t1 >= -0.01f) {
@@ -596,7 +596,7 @@ static inline bool sphere_intersect(const Ray& ray, float& t0, float& t1) {  // 
     return false;
 }
 bool UnitSphere::hit(const Ray& ray, float t_max, HitResult& h) const {  // sphere.rs:36-60
-    g_cnt.spheres_tested++;
+    g_cnt.sphere();
     float t0, t1;
     if (!sphere_intersect(ray, t0, t1)) return false;
     float t;
@@ -612,7 +612,7 @@ bool UnitSphere::hit(const Ray& ray, float t_max, HitResult& h) const {  // sphe
     return true;
 }
 bool UnitSphere::is_hit(const Ray& ray, float t_max) const {  // sphere.rs:62-69
-    g_cnt.spheres_tested++;
+    g_cnt.sphere();
     float t0, t1;
     if (sphere_intersect(ray, t0, t1)) return t0 <= t_max && t1 >= 0.0f;
     return false;
@@ -631,7 +631,7 @@ static inline void ray_box_intersection(const Ray& ray, V3 mn, V3 mx, float& t0,
     t1 = min3(max2(a[0], b[0]), max2(a[1], b[1]), max2(a[2], b[2]));
 }
 bool UnitCuboid::hit(const Ray& ray, float t_max, HitResult& h) const {  // cuboid.rs:19-48
-    g_cnt.cuboids_tested++;
+    g_cnt.cuboid();
     float t0, t1;
     ray_box_intersection(ray, -V3::fill(1.0f), V3::fill(1.0f), t0, t1);
     float t;
@@ -650,7 +650,7 @@ bool UnitCuboid::hit(const Ray& ray, float t_max, HitResult& h) const {  // cubo
     return true;
 }
 bool UnitCuboid::is_hit(const Ray& ray, float t_max) const {  // cuboid.rs:50-54
-    g_cnt.cuboids_tested++;
+    g_cnt.cuboid();
     float t0, t1;
     ray_box_intersection(ray, -V3::fill(1.0f), V3::fill(1.0f), t0, t1);
     return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
@@ -673,7 +673,7 @@ bool Cuboid::hit(const Ray& ray, float t_max, HitResult& h) const {  // cuboid.r
     return false;
 }
 bool Cuboid::is_hit(const Ray& ray, float t_max) const {  // cuboid.rs:95-100
-    g_cnt.cuboids_tested++;
+    g_cnt.cuboid();
     float t0, t1;
     ray_box_intersection(ray, center - extent, center + extent, t0, t1);
     return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
@@ -883,7 +883,9 @@ Color WhittedIntegrator::illumination(const Scene& scene, const Light& light, V3
         bool visible = true;
         if (!(t_max == 0.0f)) {
             g_cnt.any_rays++;
+            g_cnt.in_any = true;
             visible = !scene.root->is_hit(ray, t_max);
+            g_cnt.in_any = false;
         }
         if (visible) total = total + ill;
     }

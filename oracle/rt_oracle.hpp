@@ -173,13 +173,23 @@ struct HitResult {
 };
 
 struct Counters {
+    // visit counts of the reference-order traversal; the *_any fields count the part of each total
+    // that was spent inside occlusion (is_hit) queries
     uint64_t nodes_visited = 0, tris_tested = 0, spheres_tested = 0, cuboids_tested = 0;
     uint64_t closest_rays = 0, any_rays = 0, degenerate_tris = 0;
+    uint64_t nodes_visited_any = 0, tris_tested_any = 0, spheres_tested_any = 0, cuboids_tested_any = 0;
+    bool in_any = false;  // set while an is_hit query runs on this thread
     void add(const Counters& o) {
         nodes_visited += o.nodes_visited; tris_tested += o.tris_tested;
         spheres_tested += o.spheres_tested; cuboids_tested += o.cuboids_tested;
         closest_rays += o.closest_rays; any_rays += o.any_rays; degenerate_tris += o.degenerate_tris;
+        nodes_visited_any += o.nodes_visited_any; tris_tested_any += o.tris_tested_any;
+        spheres_tested_any += o.spheres_tested_any; cuboids_tested_any += o.cuboids_tested_any;
     }
+    void node() { nodes_visited++; if (in_any) nodes_visited_any++; }
+    void tri() { tris_tested++; if (in_any) tris_tested_any++; }
+    void sphere() { spheres_tested++; if (in_any) spheres_tested_any++; }
+    void cuboid() { cuboids_tested++; if (in_any) cuboids_tested_any++; }
 };
 extern thread_local Counters g_cnt;
 

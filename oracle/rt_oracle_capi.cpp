@@ -269,15 +269,16 @@ static void run_parallel(size_t n, int threads, const std::function<void(size_t,
     for (auto& th : pool) th.join();
     if (total) for (auto& c : per) total->add(c);
 }
-static void export_counters(const Counters& c, uint64_t out[8]) {
+static void export_counters(const Counters& c, uint64_t out[12]) {
     if (!out) return;
     out[0] = c.nodes_visited; out[1] = c.tris_tested; out[2] = c.spheres_tested; out[3] = c.cuboids_tested;
     out[4] = c.closest_rays; out[5] = c.any_rays; out[6] = c.degenerate_tris; out[7] = 0;
+    out[8] = c.nodes_visited_any; out[9] = c.tris_tested_any; out[10] = c.spheres_tested_any; out[11] = c.cuboids_tested_any;
 }
 
 // Scene::root.hit(ray, t_max) per ray (integrator.rs:64).  prim = 0xFFFFFFFF and obj = -1 on a miss.
 int orc_trace_closest(void* p, size_t n, const float* const rays[7], int32_t* obj, uint32_t* prim, float* t,
-                      float* u, float* v, float* t_local, float* pos3, float* norm3, int threads, uint64_t counters[8]) {
+                      float* u, float* v, float* t_local, float* pos3, float* norm3, int threads, uint64_t counters[12]) {
     OrcScene* s = (OrcScene*)p;
     Counters total;
     run_parallel(n, threads, [&](size_t b, size_t e) {
@@ -300,14 +301,16 @@ int orc_trace_closest(void* p, size_t n, const float* const rays[7], int32_t* ob
     return 0;
 }
 // Scene::root.is_hit(ray, t_max) per ray (integrator.rs:124).
-int orc_trace_any(void* p, size_t n, const float* const rays[7], uint8_t* out, int threads, uint64_t counters[8]) {
+int orc_trace_any(void* p, size_t n, const float* const rays[7], uint8_t* out, int threads, uint64_t counters[12]) {
     OrcScene* s = (OrcScene*)p;
     Counters total;
     run_parallel(n, threads, [&](size_t b, size_t e) {
         for (size_t k = b; k < e; k++) {
             Ray ray(V3(rays[0][k], rays[1][k], rays[2][k]), V3(rays[3][k], rays[4][k], rays[5][k]));
             g_cnt.any_rays++;
+            g_cnt.in_any = true;
             out[k] = s->scene.root->is_hit(ray, rays[6][k]) ? 1 : 0;
+            g_cnt.in_any = false;
         }
     }, &total);
     export_counters(total, counters);
@@ -331,7 +334,7 @@ int orc_primary_rays(void* p, int x0, int y0, int w, int h, float* const rays[7]
 // parallel_render (render.rs:10-56) restricted to the rect: worker threads pull 100-pixel chunks from
 // a shared counter; params = {max_depth, shadow_rays, scatter_rays, antialiasing}.  out is row-major
 // w*h*3 floats.  Returns the wall time of the pixel loop in seconds.
-double orc_render(void* p, const int params[4], int x0, int y0, int w, int h, float* out, int threads, uint64_t counters[8]) {
+double orc_render(void* p, const int params[4], int x0, int y0, int w, int h, float* out, int threads, uint64_t counters[12]) {
     OrcScene* s = (OrcScene*)p;
     WhittedIntegrator integ;
     integ.max_depth = params[0]; integ.shadow_rays = params[1]; integ.scatter_rays = params[2]; integ.antialiasing = params[3];

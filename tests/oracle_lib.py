@@ -65,7 +65,7 @@ def _fp(a):
 
 
 COUNTER_NAMES = ("nodes_visited", "tris_tested", "spheres_tested", "cuboids_tested", "closest_rays", "any_rays",
-                 "degenerate_tris", "_")
+                 "degenerate_tris", "_", "nodes_visited_any", "tris_tested_any", "spheres_tested_any", "cuboids_tested_any")
 
 
 def load_skybox(max_width=None):
@@ -160,7 +160,7 @@ class OracleScene:
         obj = np.zeros(n, np.int32); prim = np.zeros(n, np.uint32)
         t = np.zeros(n, np.float32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
         tl = np.zeros(n, np.float32); pos = np.zeros((n, 3), np.float32); nrm = np.zeros((n, 3), np.float32)
-        cnt = np.zeros(8, np.uint64)
+        cnt = np.zeros(12, np.uint64)
         lib().orc_trace_closest(self.h, n, self._ray_ptrs(rays), obj.ctypes.data_as(_i32p), prim.ctypes.data_as(_u32p),
                                 _fp(t), _fp(u), _fp(v), _fp(tl), _fp(pos), _fp(nrm), threads, cnt.ctypes.data_as(_u64p))
         res = dict(obj=obj, prim=prim, t=t, u=u, v=v, counters=dict(zip(COUNTER_NAMES, cnt.tolist())))
@@ -172,7 +172,7 @@ class OracleScene:
         n = rays.shape[1]
         threads = threads or os.cpu_count() or 1
         out = np.zeros(n, np.uint8)
-        cnt = np.zeros(8, np.uint64)
+        cnt = np.zeros(12, np.uint64)
         lib().orc_trace_any(self.h, n, self._ray_ptrs(rays), out.ctypes.data_as(_u8p), threads, cnt.ctypes.data_as(_u64p))
         return out, dict(zip(COUNTER_NAMES, cnt.tolist()))
 
@@ -182,7 +182,7 @@ class OracleScene:
         threads = threads or os.cpu_count() or 1
         out = np.zeros((h, w, 3), np.float32)
         params = (C.c_int * 4)(max_depth, shadow_rays, scatter_rays, antialiasing)
-        cnt = np.zeros(8, np.uint64)
+        cnt = np.zeros(12, np.uint64)
         sec = lib().orc_render(self.h, params, x0, y0, w, h, _fp(out), threads, cnt.ctypes.data_as(_u64p))
         return out, sec, dict(zip(COUNTER_NAMES, cnt.tolist()))
 
