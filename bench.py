@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--workload", default="bunny_1080x960_64spp_depth5", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small-sky", action="store_true", help="use a strided skybox (debug)")
+    ap.add_argument("--opt", default="", help="tuning overrides, e.g. chunk=128,blocks=3,lds=0,max_paths=2097152")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +106,10 @@ def main():
     cam_wh, aa, max_depth, shadow_rays = WORKLOADS[args.workload]
     sky = rt.load_skybox(max_width=1024 if args.small_sky else None)
     scene = rt.Scene.main(sky=sky, cam=cam_wh).upload(local_rank)
+    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "max_paths": rt.OPT_MAX_PATHS}
+    for kv in filter(None, args.opt.split(",")):
+        k, v = kv.split("=")
+        scene.set_option(opt_ids[k], int(v))
     W, H = cam_wh
     region = rt.Scene.make_region(W, H, tile=(TILE, TILE), tile_first=rank, tile_stride=world)
     n_px = rt.Scene.region_pixels(region)
@@ -158,10 +163,15 @@ def main():
         if not args.no_cpu_baseline:
             cpu, cnt = cpu_baseline(sky, cam_wh, aa, max_depth, shadow_rays)
         if cnt is not None and kt["closest_launches"]:
+            # k_wave_trace carries the closest-hit rays of a bounce plus the shadow rays of the previous one; the
+            # launch that ends a sample carries shadow rays only.  All its launches are pooled.
             b_closest, b_any = byte_model(cnt)
-            avg_ms = kt["closest_ms"] / kt["closest_launches"]
-            rays_per_launch = st["closest_rays"] / kt["closest_launches"]
-            achieved = rays_per_launch * b_closest / (avg_ms * 1e-3) / 1e9
+            n_launch = kt["closest_launches"] + kt["any_launches"]
+            trace_ms = kt["closest_ms"] + kt["any_ms"]
+            avg_ms = trace_ms / n_launch
+            rays_per_launch = (st["closest_rays"] + st["any_rays"]) / n_launch
+            bytes_per_launch = (st["closest_rays"] * b_closest + st["any_rays"] * b_any) / n_launch
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
             if os.path.exists(tpath):
@@ -172,16 +182,12 @@ def main():
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "kernel": "k_wave_trace (closest-hit trace of the wavefront queue)",
-                        "avg_launch_ms": avg_ms, "launches": kt["closest_launches"], "rays_per_launch": rays_per_launch,
-                        "algorithmic_bytes_per_ray": b_closest,
-                        "stream_only_gbs": rays_per_launch * 48.0 / (avg_ms * 1e-3) / 1e9}
-            extra["any_hit_kernel"] = {"avg_launch_ms": kt["any_ms"] / max(1, kt["any_launches"]), "launches": kt["any_launches"],
-                                       "algorithmic_bytes_per_ray": b_any,
-                                       "mrays_per_s": st["any_rays"] / max(1e-9, kt["any_ms"] * 1e-3) / 1e6}
-            extra["closest_hit_kernel_mrays_per_s"] = st["closest_rays"] / (kt["closest_ms"] * 1e-3) / 1e6
-            extra["stage_ms_per_frame"] = {"trace_closest": kt["closest_ms"], "trace_any": kt["any_ms"], "shade": st["shade_ms"],
-                                           "device_total": st["device_ms"]}
+                        "traffic": traffic, "kernel": "k_wave_trace (persistent closest-hit + any-hit traversal of the wavefront queues)",
+                        "avg_launch_ms": avg_ms, "launches": n_launch, "rays_per_launch": rays_per_launch,
+                        "algorithmic_bytes_per_closest_ray": b_closest, "algorithmic_bytes_per_any_ray": b_any,
+                        "stream_only_gbs": (st["closest_rays"] * 48.0 + st["any_rays"] * 36.0) / (trace_ms * 1e-3) / 1e9}
+            extra["trace_kernel_mrays_per_s"] = (st["closest_rays"] + st["any_rays"]) / (trace_ms * 1e-3) / 1e6
+            extra["stage_ms_per_frame"] = {"trace": trace_ms, "shade_resolve": st["shade_ms"], "device_total": st["device_ms"]}
 
     if rank == 0:
         value = rays / elapsed / 1e6

@@ -204,7 +204,9 @@ typedef struct rtamd_stats {
     uint64_t paths;        /* integrate_recur(depth 0) calls, src/integrator.rs:45 */
     uint64_t launches;     /* kernels launched */
     double device_ms;      /* HIP-event time of the whole render on the context's stream */
-    double trace_closest_ms, trace_any_ms, shade_ms; /* filled when profiling is enabled */
+    /* filled when profiling is enabled: trace launches that carry closest-hit rays (they also carry the previous
+     * bounce's shadow rays), the shadow-only launch that ends a sample, shade + resolve launches */
+    double trace_closest_ms, trace_any_ms, shade_ms;
 } rtamd_stats;
 
 /* ---- entry points ------------------------------------------------------------------------------ */
@@ -251,7 +253,10 @@ int rtamd_quantize_device(rtamd_context* ctx, const float* rgb_device, size_t n,
 enum rtamd_option {
     RTAMD_OPT_PROFILE = 0,      /* 1: time each stage with HIP events (slower; fills *_ms) */
     RTAMD_OPT_MAX_PATHS = 1,    /* pixels processed per wavefront chunk */
-    RTAMD_OPT_LDS_SCENE = 2     /* 1 (default): stage small meshes in LDS; 0: always read through L2 */
+    RTAMD_OPT_LDS_SCENE = 2,    /* 1 (default): stage small meshes in LDS; 0: always read through L2 */
+    RTAMD_OPT_SCHEDULER = 3,    /* batch trace entry points: 1 (default) persistent phase-voting kernel, 0 plain nested loops */
+    RTAMD_OPT_CHUNK = 4,        /* rays a wave dequeues per queue-head atomic (power of two, 64..4096) */
+    RTAMD_OPT_BLOCKS_PER_CU = 5 /* persistent 512-thread blocks per CU (1..8) */
 };
 int rtamd_set_option(rtamd_context* ctx, int option, int64_t value);
 /* Average duration (ms) and launch count of the closest-hit / any-hit trace kernels since the last

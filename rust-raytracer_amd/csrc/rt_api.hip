@@ -37,6 +37,7 @@ struct rtamd_context {
     // ray batch workspace of the host-pointer entry points
     void* batch_buf = nullptr;
     size_t batch_bytes = 0;
+    uint32_t* work_head = nullptr;   // queue head of the batch trace kernels
 
     // kernel timing (RTAMD_OPT_PROFILE)
     double closest_ms = 0, any_ms = 0, shade_ms = 0;
@@ -130,7 +131,10 @@ int ensure_wave(rtamd_context* ctx, size_t cap, uint32_t samples) {
     ctx->wave_cap = 0; ctx->wave_samples = 0;
     WaveBufs& W = ctx->W;
     int rc;
+    const size_t S = samples ? samples : 1;
+    if (cap * S > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "chunk size x light samples exceeds 2^32; lower RTAMD_OPT_MAX_PATHS");
     W.cap = (uint32_t)cap;
+    W.any_cap = (uint32_t)(cap * S);
     if ((rc = wave_alloc(ctx, &W.rng_lo, cap))) return rc;
     if ((rc = wave_alloc(ctx, &W.rng_hi, cap))) return rc;
     if ((rc = wave_alloc(ctx, &W.sum, 3 * cap))) return rc;
@@ -140,12 +144,16 @@ int ensure_wave(rtamd_context* ctx, size_t cap, uint32_t samples) {
         if ((rc = wave_alloc(ctx, &W.q_slot[k], cap))) return rc;
         if ((rc = wave_alloc(ctx, &W.q_ray[k], 6 * cap))) return rc;
     }
-    if ((rc = wave_alloc(ctx, &W.h_mat, cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.h_f, 8 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.h_obj, cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.h_prim, cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.h_f, 3 * cap))) return rc;
     if ((rc = wave_alloc(ctx, &W.lit_slot, cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.lit_f, 9 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.smp, (size_t)7 * (samples ? samples : 1) * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.counts, (size_t)16))) return rc;
+    if ((rc = wave_alloc(ctx, &W.lit_f, 6 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.smp, 4 * S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.a_ray, 7 * S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.a_vidx, S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.vis, S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, &W.counts, (size_t)CounterSlots::TOTAL))) return rc;
     if ((rc = wave_alloc(ctx, &W.stats, (size_t)16))) return rc;
     ctx->wave_cap = cap; ctx->wave_samples = samples;
     return RTAMD_OK;
@@ -235,6 +243,11 @@ int rtamd_create(int device_id, rtamd_context** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->cfg.num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void**)&ctx->work_head, 256) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return RTAMD_E_DEVICE;
+    }
     *out = ctx;
     return RTAMD_OK;
 }
@@ -246,6 +259,7 @@ void rtamd_destroy(rtamd_context* ctx) {
     free_list(ctx->scene_allocs);
     free_list(ctx->wave_allocs);
     if (ctx->batch_buf) (void)hipFree(ctx->batch_buf);
+    if (ctx->work_head) (void)hipFree(ctx->work_head);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -262,6 +276,15 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
             ctx->max_paths = (size_t)value;
             return RTAMD_OK;
         case RTAMD_OPT_LDS_SCENE: ctx->cfg.use_lds = value != 0; return RTAMD_OK;
+        case RTAMD_OPT_SCHEDULER: ctx->cfg.scheduler = value != 0; return RTAMD_OK;
+        case RTAMD_OPT_CHUNK:
+            if (value < 64 || value > 4096 || (value & (value - 1))) return fail(ctx, RTAMD_E_INVALID, "chunk must be a power of two in [64, 4096]");
+            ctx->cfg.chunk = (int)value;
+            return RTAMD_OK;
+        case RTAMD_OPT_BLOCKS_PER_CU:
+            if (value < 1 || value > 8) return fail(ctx, RTAMD_E_INVALID, "blocks per CU must be in [1, 8]");
+            ctx->cfg.sched_blocks_per_cu = (int)value;
+            return RTAMD_OK;
         default: return fail(ctx, RTAMD_E_INVALID, "unknown option");
     }
 }
@@ -435,13 +458,13 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
 int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream) {
     if (!ctx || !rays || !out) return RTAMD_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
-    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_E_INVALID, "at most 2^32-1 rays per call");
+    if (n > 0x7FFFFFFFull) return fail(ctx, RTAMD_E_INVALID, "at most 2^31-1 rays per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
     HitBatch hb{out->obj, out->prim, out->t, out->u, out->v};
     timed_begin(ctx, 0, st);
-    HIP_TRY(ctx, launch_trace_closest(ctx->S, ctx->cfg, rb, hb, n, st));
+    HIP_TRY(ctx, launch_trace_closest(ctx->S, ctx->cfg, rb, hb, n, ctx->work_head, st));
     timed_end(ctx, st);
     if (!stream) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -453,12 +476,12 @@ int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_
 int rtamd_trace_any_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out, void* stream) {
     if (!ctx || !rays || !out) return RTAMD_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
-    if (n > 0xFFFFFFFFull) return fail(ctx, RTAMD_E_INVALID, "at most 2^32-1 rays per call");
+    if (n > 0x7FFFFFFFull) return fail(ctx, RTAMD_E_INVALID, "at most 2^31-1 rays per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
     timed_begin(ctx, 1, st);
-    HIP_TRY(ctx, launch_trace_any(ctx->S, ctx->cfg, rb, out, n, st));
+    HIP_TRY(ctx, launch_trace_any(ctx->S, ctx->cfg, rb, out, n, ctx->work_head, st));
     timed_end(ctx, st);
     if (!stream) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -522,6 +545,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     if (integ->antialiasing < 1) return fail(ctx, RTAMD_E_INVALID, "antialiasing must be >= 1");
     if (integ->scatter_rays != 1) return fail(ctx, RTAMD_E_UNSUPPORTED, "only scatter_rays = 1 is supported on the device");
     if (integ->shadow_rays < 1) return fail(ctx, RTAMD_E_INVALID, "shadow_rays must be >= 1");
+    if (integ->max_depth > (int)CounterSlots::MAX_DEPTH) return fail(ctx, RTAMD_E_INVALID, "max_depth above 64 is not supported");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     uint32_t S_total = 0;
@@ -548,31 +572,45 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     HIP_TRY(ctx, hipEventRecord(ev0, st));
     uint64_t launches = 0;
     const uint32_t aa = (uint32_t)integ->antialiasing;
+    const int D = integ->max_depth;
+    typedef CounterSlots CS;
     for (size_t begin = 0; begin < total_slots; begin += cap) {
         const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
+        const size_t any_upper = (size_t)chunk_n * (S_total ? S_total : 1);
         for (uint32_t si = 0; si < aa; si++) {
             for (uint32_t sj = 0; sj < aa; sj++) {
-                HIP_TRY(ctx, hipMemsetAsync(W.counts, 0, 16, st));
-                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, si == 0 && sj == 0, st));
+                HIP_TRY(ctx, hipMemsetAsync(W.counts, 0, CS::TOTAL * 4, st));
+                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, si == 0 && sj == 0, CS::Q + 0, st));
                 launches++;
                 uint32_t cur = 0;
-                if (integ->max_depth <= 0) {
-                    HIP_TRY(ctx, launch_mark_miss(W, chunk_n, st));
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, 0, 1, integ->shadow_rays, chunk_n, st));
+                if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
+                    HIP_TRY(ctx, launch_mark_miss(W, CS::Q + 0, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, 0, 1, integ->shadow_rays, CS::Q + 0, CS::Q + 1, CS::LIT + 0, CS::ANY + 0, chunk_n, st));
                     launches += 2;
                 }
-                for (int depth = 0; depth < integ->max_depth; depth++) {
+                for (int d = 0; d < D; d++) {
+                    // trace: closest-hit rays of bounce d together with the shadow rays of bounce d-1
                     timed_begin(ctx, 0, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, CS::Q + d, d > 0 ? CS::ANY + (d - 1) : MISS, CS::HEAD + d,
+                                                   chunk_n + (d > 0 ? any_upper : 0), st));
                     timed_end(ctx, st);
+                    launches++;
                     timed_begin(ctx, 2, st);
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, depth, integ->max_depth, integ->shadow_rays, chunk_n, st));
+                    if (d > 0) {
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, integ->shadow_rays, CS::LIT + (d - 1), chunk_n, st));
+                        launches++;
+                    }
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, d, D, integ->shadow_rays, CS::Q + d, CS::Q + d + 1, CS::LIT + d, CS::ANY + d, chunk_n, st));
                     timed_end(ctx, st);
-                    timed_begin(ctx, 1, st);
-                    HIP_TRY(ctx, launch_wave_shadow(ctx->S, ctx->cfg, W, integ->shadow_rays, chunk_n, st));
-                    timed_end(ctx, st);
-                    launches += 3;
+                    launches++;
                     cur ^= 1;
+                }
+                if (D > 0) {  // shadow rays of the last bounce
+                    timed_begin(ctx, 1, st);
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, MISS, CS::ANY + (D - 1), CS::HEAD + D, any_upper, st));
+                    timed_end(ctx, st);
+                    HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, integ->shadow_rays, CS::LIT + (D - 1), chunk_n, st));
+                    launches += 2;
                 }
             }
         }

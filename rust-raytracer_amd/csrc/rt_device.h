@@ -290,6 +290,56 @@ struct Best {
     float t_local, u, v;
 };
 
+// Closest-hit test of a non-mesh primitive in object space: UnitSphere::hit (sphere.rs:36-45),
+// Cuboid::hit -> UnitCuboid::hit (cuboid.rs:82-93,19-28), Triangle::hit (triangle.rs:41-44).
+// u, v are only produced for the triangle; sphere / cuboid uv come from reconstruct_hit().
+__device__ __forceinline__ bool primitive_closest(const DevScene& S, const DevObject& ob, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
+    if (ob.geom_kind == GEOM_UNIT_SPHERE) {
+        return unit_sphere_hit(pos, dir, t_max, t);
+    } else if (ob.geom_kind == GEOM_CUBOID) {
+        const DevCuboid c = S.cuboids[ob.geom_index];
+        f3 ie = mk(c.inv_extent[0], c.inv_extent[1], c.inv_extent[2]);
+        f3 p = (pos - mk(c.center[0], c.center[1], c.center[2])) * ie;  // cuboid.rs:83-85
+        f3 d = dir * ie;
+        return unit_cuboid_hit(p, d, t_max, t);
+    } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {
+        return unit_cuboid_hit(pos, dir, t_max, t);
+    } else {  // GEOM_TRIANGLE
+        const DevTriangle tr = S.triangles[ob.geom_index];
+        f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
+        f3 ab = mk(tr.b[0], tr.b[1], tr.b[2]) - a, ac = mk(tr.c[0], tr.c[1], tr.c[2]) - a;
+        float4 q0 = make_float4(a.x, a.y, a.z, ab.x), q1 = make_float4(ab.y, ab.z, ac.x, ac.y), q2 = make_float4(ac.z, 0.f, 0.f, 0.f);
+        return tri_test(q0, q1, q2, pos, dir, t_max, t, u, v);
+    }
+}
+// Occlusion test of a non-mesh primitive: UnitSphere::is_hit (sphere.rs:63-69), Cuboid::is_hit
+// (cuboid.rs:95-100, world-space slab with Ray::inv_dir), UnitCuboid::is_hit (cuboid.rs:50-54),
+// Triangle::is_hit (triangle.rs:59-62).
+__device__ __forceinline__ bool primitive_any(const DevScene& S, const DevObject& ob, f3 pos, f3 dir, float t_max) {
+    if (ob.geom_kind == GEOM_UNIT_SPHERE) {
+        return unit_sphere_any(pos, dir, t_max);
+    } else if (ob.geom_kind == GEOM_CUBOID) {
+        const DevCuboid c = S.cuboids[ob.geom_index];
+        f3 ctr = mk(c.center[0], c.center[1], c.center[2]), ext = mk(c.extent[0], c.extent[1], c.extent[2]);
+        f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        float t0, t1;
+        box_roots(pos, inv, ctr - ext, ctr + ext, t0, t1);
+        return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
+    } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {
+        f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        float t0, t1;
+        box_roots(pos, inv, fill(-1.0f), fill(1.0f), t0, t1);
+        return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
+    } else {
+        const DevTriangle tr = S.triangles[ob.geom_index];
+        f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
+        f3 ab = mk(tr.b[0], tr.b[1], tr.b[2]) - a, ac = mk(tr.c[0], tr.c[1], tr.c[2]) - a;
+        float4 q0 = make_float4(a.x, a.y, a.z, ab.x), q1 = make_float4(ab.y, ab.z, ac.x, ac.y), q2 = make_float4(ac.z, 0.f, 0.f, 0.f);
+        float t, u, v;
+        return tri_test(q0, q1, q2, pos, dir, t_max, t, u, v);
+    }
+}
+
 // Object::hit (src/geom/aggregate.rs:104-111) for the closest-hit query: returns true and shrinks
 // t_max (caller's space) when the object is hit within t_max.
 template <class Mem>
@@ -309,22 +359,8 @@ __device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds
             hit = traverse_mesh<false>(gm, m.n_nodes, pos, dir, tl_max, prim, u, v);
         }
         t = tl_max;
-    } else if (ob.geom_kind == GEOM_UNIT_SPHERE) {
-        hit = unit_sphere_hit(pos, dir, tl_max, t);
-    } else if (ob.geom_kind == GEOM_CUBOID) {
-        const DevCuboid c = S.cuboids[ob.geom_index];
-        f3 ie = mk(c.inv_extent[0], c.inv_extent[1], c.inv_extent[2]);
-        f3 p = (pos - mk(c.center[0], c.center[1], c.center[2])) * ie;  // cuboid.rs:83-85
-        f3 d = dir * ie;
-        hit = unit_cuboid_hit(p, d, tl_max, t);
-    } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {
-        hit = unit_cuboid_hit(pos, dir, tl_max, t);
-    } else {  // GEOM_TRIANGLE (triangle.rs:41-57)
-        const DevTriangle tr = S.triangles[ob.geom_index];
-        f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
-        f3 ab = mk(tr.b[0], tr.b[1], tr.b[2]) - a, ac = mk(tr.c[0], tr.c[1], tr.c[2]) - a;
-        float4 q0 = make_float4(a.x, a.y, a.z, ab.x), q1 = make_float4(ab.y, ab.z, ac.x, ac.y), q2 = make_float4(ac.z, 0.f, 0.f, 0.f);
-        hit = tri_test(q0, q1, q2, pos, dir, tl_max, t, u, v);
+    } else {
+        hit = primitive_closest(S, ob, pos, dir, tl_max, t, u, v);
     }
     if (hit) {
         best.obj = oi; best.prim = prim; best.t_local = t; best.u = u; best.v = v;
@@ -346,28 +382,8 @@ __device__ __forceinline__ bool object_any(const DevScene& S, const Mem* lds_mem
         }
         GlobalMem gm{S.nodes + 2 * (size_t)m.node_base, S.tris + 3 * (size_t)m.tri_base};
         return traverse_mesh<true>(gm, m.n_nodes, pos, dir, t_max, prim, u, v);
-    } else if (ob.geom_kind == GEOM_UNIT_SPHERE) {
-        return unit_sphere_any(pos, dir, t_max);
-    } else if (ob.geom_kind == GEOM_CUBOID) {  // cuboid.rs:95-100: world-space slab with Ray::inv_dir
-        const DevCuboid c = S.cuboids[ob.geom_index];
-        f3 ctr = mk(c.center[0], c.center[1], c.center[2]), ext = mk(c.extent[0], c.extent[1], c.extent[2]);
-        f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-        float t0, t1;
-        box_roots(pos, inv, ctr - ext, ctr + ext, t0, t1);
-        return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
-    } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {  // cuboid.rs:50-54
-        f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-        float t0, t1;
-        box_roots(pos, inv, fill(-1.0f), fill(1.0f), t0, t1);
-        return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
-    } else {  // triangle.rs:59-62
-        const DevTriangle tr = S.triangles[ob.geom_index];
-        f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
-        f3 ab = mk(tr.b[0], tr.b[1], tr.b[2]) - a, ac = mk(tr.c[0], tr.c[1], tr.c[2]) - a;
-        float4 q0 = make_float4(a.x, a.y, a.z, ab.x), q1 = make_float4(ab.y, ab.z, ac.x, ac.y), q2 = make_float4(ac.z, 0.f, 0.f, 0.f);
-        float t, u, v;
-        return tri_test(q0, q1, q2, pos, dir, t_max, t, u, v);
     }
+    return primitive_any(S, ob, pos, dir, t_max);
 }
 
 // GeometryList::hit (src/geom/aggregate.rs:24-35) over the root items; an object tree item is

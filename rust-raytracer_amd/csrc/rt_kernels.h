@@ -23,41 +23,61 @@ struct RegionDev {
 // reads 64 consecutive floats per component.
 struct WaveBufs {
     uint32_t cap;
+    uint32_t any_cap;     // capacity of the shadow-ray queue = cap * light samples per lit hit
     // per pixel slot, persistent over the samples of the pixel
     uint64_t* rng_lo;     // SmallRng state, low / high half
     uint64_t* rng_hi;
     float* sum;           // 3*cap: sum of finished samples
     float* L;             // 3*cap: radiance of the sample in flight
     float* beta;          // 3*cap: path throughput
-    // ray queues, double buffered by bounce parity
+    // closest-hit ray queues, double buffered by bounce parity
     uint32_t* q_slot[2];  // cap: pixel slot of the path
     float* q_ray[2];      // 6*cap: pos.xyz, dir.xyz
-    // hit records of the current queue
-    uint32_t* h_mat;      // cap: material index or MISS
-    float* h_f;           // 8*cap: u, v, pos.xyz, norm.xyz
+    // hit records of the current queue (what Geometry::hit found; the shade stage rebuilds pos / normal)
+    uint32_t* h_obj;      // cap: object index or MISS
+    uint32_t* h_prim;     // cap
+    float* h_f;           // 3*cap: t in the object's space, u, v
     // lit queue: paths whose hit has a non-black diffuse colour
     uint32_t* lit_slot;   // cap
-    float* lit_f;         // 9*cap: p.xyz, beta.xyz, diffuse.xyz
-    float* smp;           // 7*S*cap: per light sample dir.xyz, t_max, ill.xyz
-    uint32_t* counts;     // [0],[1]: queue lengths, [2]: lit queue length
+    float* lit_f;         // 6*cap: beta.xyz, diffuse.xyz
+    float* smp;           // 4*S*cap: per light sample t_max, ill.xyz
+    // shadow-ray queue of the bounce
+    float* a_ray;         // 7*any_cap: pos.xyz, dir.xyz, t_max
+    uint32_t* a_vidx;     // any_cap: index into vis (sample * cap + lit index)
+    uint8_t* vis;         // S*cap: 1 = occluded
+    // counters, zeroed once per sample pass: see CounterSlots
+    uint32_t* counts;
     uint64_t* stats;      // [0] closest-hit rays, [1] any-hit rays
+};
+// Layout of WaveBufs::counts.  Every bounce has its own slots, so nothing is reset inside a pass.
+struct CounterSlots {
+    static constexpr uint32_t MAX_DEPTH = 64;
+    static constexpr uint32_t Q = 0;                    // Q + d   : paths entering bounce d
+    static constexpr uint32_t LIT = Q + MAX_DEPTH + 1;  // LIT + d : lit hits of bounce d
+    static constexpr uint32_t ANY = LIT + MAX_DEPTH;    // ANY + d : shadow rays of bounce d
+    static constexpr uint32_t HEAD = ANY + MAX_DEPTH;   // HEAD + d: work-queue head of trace launch d
+    static constexpr uint32_t TOTAL = HEAD + MAX_DEPTH + 1;
 };
 
 struct LaunchCfg {
     int num_cus = 256;
-    int trace_blocks_per_cu = 4;
+    int trace_blocks_per_cu = 4;   // grid-stride kernels
+    int sched_blocks_per_cu = 2;   // persistent scheduler kernels (512 threads each)
+    int chunk = 256;               // rays a wave dequeues per atomic
     int use_lds = 1;
+    int scheduler = 1;             // 1: persistent phase-voting scheduler, 0: plain nested-loop kernels (batch entry points only)
 };
 
-hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, hipStream_t st);
-hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, uint8_t* out, size_t n, hipStream_t st);
+hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st);
+hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, uint8_t* out, size_t n, uint32_t* work_head, hipStream_t st);
 hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
-                         uint32_t si, uint32_t sj, uint32_t aa, bool first, hipStream_t st);
-hipError_t launch_mark_miss(const WaveBufs& W, size_t upper, hipStream_t st);
-hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, size_t upper, hipStream_t st);
+                         uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t q_idx, hipStream_t st);
+hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st);
+hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
+                             uint32_t head_idx, size_t upper, hipStream_t st);
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
-                             int shadow_rays, size_t upper, hipStream_t st);
-hipError_t launch_wave_shadow(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, size_t upper, hipStream_t st);
+                             int shadow_rays, uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st);
+hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, size_t upper, hipStream_t st);
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 

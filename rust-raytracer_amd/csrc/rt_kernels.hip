@@ -6,6 +6,7 @@
 // grid that covers the chip and walks its queue with a grid stride; the queue length is read from
 // device memory, so the host never synchronises inside a frame.
 #include "rt_kernels.h"
+#include "rt_sched.h"
 
 namespace rtamd {
 
@@ -76,6 +77,52 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene S, RayBatch 
         f3 dir = mk(rays.dx[i], rays.dy[i], rays.dz[i]);
         out[i] = scene_any(S, lm, pos, dir, rays.tmax[i]) ? 1 : 0;
     }
+}
+
+// Scheduler versions of the two batch kernels (see rt_sched.h).
+template <bool USE_LDS>
+__device__ __forceinline__ LdsMesh stage_mesh_sched(const DevScene& S) {
+    LdsMesh l{nullptr, nullptr};
+    if (USE_LDS) {
+        LdsMem mem;
+        stage_mesh<true>(S, mem);
+        l.nodes = mem.nodes; l.tris = mem.tris;
+    }
+    return l;
+}
+
+struct BatchIO {
+    DevScene S;
+    RayBatch rays;
+    HitBatch hits;
+    uint8_t* any_out;
+    bool any_mode;
+    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any) const {
+        pos = mk(rays.ox[i], rays.oy[i], rays.oz[i]);
+        dir = mk(rays.dx[i], rays.dy[i], rays.dz[i]);
+        tmax = rays.tmax[i];
+        any = any_mode;
+    }
+    __device__ __forceinline__ void store_closest(uint32_t i, bool found, const Best& b, float t_world) const {
+        float hu = b.u, hv = b.v;
+        if (found && S.objects[b.obj].geom_kind != GEOM_MESH && S.objects[b.obj].geom_kind != GEOM_TRIANGLE) {
+            f3 hp, hn;  // sphere / cuboid uv need the hit point
+            reconstruct_hit(S, b, mk(rays.ox[i], rays.oy[i], rays.oz[i]), mk(rays.dx[i], rays.dy[i], rays.dz[i]), hp, hn, hu, hv);
+        }
+        hits.obj[i] = found ? b.obj : MISS;
+        hits.prim[i] = found ? b.prim : MISS;
+        hits.t[i] = found ? t_world : 0.0f;
+        hits.u[i] = found ? hu : 0.0f;
+        hits.v[i] = found ? hv : 0.0f;
+    }
+    __device__ __forceinline__ void store_any(uint32_t i, bool occluded) const { any_out[i] = occluded ? 1 : 0; }
+};
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
+    if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;  // enough earlier blocks exist to cover the batch
+    const LdsMesh lds = stage_mesh_sched<USE_LDS>(S);
+    trace_scheduler(S, lds, io, work_head, n, chunk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,7 +327,7 @@ __device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, ui
 // pixel sum (integrator.rs:50-53 adds the samples in generation order).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_raygen(WaveBufs W, RegionDev R, CameraDev cam, uint32_t chunk_begin, uint32_t chunk_n,
-                                                uint32_t si, uint32_t sj, uint32_t aa, uint32_t first_sample) {
+                                                uint32_t si, uint32_t sj, uint32_t aa, uint32_t first_sample, uint32_t q_idx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     uint32_t cx = 0, cy = 0;
@@ -308,7 +355,7 @@ __global__ __launch_bounds__(256) void k_raygen(WaveBufs W, RegionDev R, CameraD
         dir = normalize(d);
         pos = cam.pos;
     }
-    uint32_t q = wave_append(valid, &W.counts[0]);
+    uint32_t q = wave_append(valid, &W.counts[q_idx]);
     if (valid) {
         W.q_slot[0][q] = i;
         float* r = W.q_ray[0];
@@ -318,52 +365,86 @@ __global__ __launch_bounds__(256) void k_raygen(WaveBufs W, RegionDev R, CameraD
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 2: closest-hit trace of the current queue (scene.root.hit(ray, 1e12), integrator.rs:64)
-// and reconstruction of the HitResult the shading stage needs.
+// Stage 2: trace.  One persistent launch serves both ray kinds of a bounce: the closest-hit rays of
+// the current path queue (scene.root.hit(ray, 1e12), integrator.rs:64) and the shadow rays the
+// previous shade stage emitted (scene.root.is_hit(&ray, t_max), integrator.rs:124).
 // ------------------------------------------------------------------------------------------------
-template <bool USE_LDS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur) {
-    LdsMem mem;
-    const LdsMem* lm = stage_mesh<USE_LDS>(S, mem);
-    const uint32_t n = W.counts[cur];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        W.counts[cur ^ 1] = 0;   // next queue
-        W.counts[2] = 0;         // lit queue
-        W.stats[0] += n;         // closest-hit rays
-    }
-    const float* r = W.q_ray[cur];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        f3 pos = mk(r[i], r[i + W.cap], r[i + 2 * W.cap]);
-        f3 dir = mk(r[i + 3 * W.cap], r[i + 4 * W.cap], r[i + 5 * W.cap]);
-        Best b;
-        b.obj = MISS; b.prim = 0; b.t_local = 0.f; b.u = 0.f; b.v = 0.f;
-        float t_hit;
-        bool found = scene_closest(S, lm, pos, dir, 1e12f, b, t_hit);
-        if (found) {
-            f3 hp, hn;
-            float hu, hv;
-            reconstruct_hit(S, b, pos, dir, hp, hn, hu, hv);
-            W.h_mat[i] = S.objects[b.obj].material;
-            W.h_f[i] = hu; W.h_f[i + W.cap] = hv;
-            W.h_f[i + 2 * W.cap] = hp.x; W.h_f[i + 3 * W.cap] = hp.y; W.h_f[i + 4 * W.cap] = hp.z;
-            W.h_f[i + 5 * W.cap] = hn.x; W.h_f[i + 6 * W.cap] = hn.y; W.h_f[i + 7 * W.cap] = hn.z;
+struct WaveIO {
+    const float* q_ray;   // closest-hit ray queue of this bounce
+    const float* a_ray;   // shadow-ray queue
+    const uint32_t* a_vidx;
+    uint32_t* h_obj;
+    uint32_t* h_prim;
+    float* h_f;
+    uint8_t* vis;
+    uint32_t cap, any_cap;
+    uint32_t n_closest;
+    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any) const {
+        if (i < n_closest) {
+            const float* r = q_ray;
+            pos = mk(r[i], r[i + cap], r[i + 2 * cap]);
+            dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
+            tmax = 1e12f;
+            any = false;
         } else {
-            W.h_mat[i] = MISS;
+            const uint32_t j = i - n_closest;
+            const size_t ac = any_cap;
+            const float* r = a_ray;
+            pos = mk(r[j], r[j + ac], r[j + 2 * ac]);
+            dir = mk(r[j + 3 * ac], r[j + 4 * ac], r[j + 5 * ac]);
+            tmax = r[j + 6 * ac];
+            any = true;
         }
     }
+    __device__ __forceinline__ void store_closest(uint32_t i, bool found, const Best& b, float) const {
+        h_obj[i] = found ? b.obj : MISS;
+        if (found) {
+            h_prim[i] = b.prim;
+            h_f[i] = b.t_local; h_f[i + cap] = b.u; h_f[i + 2 * cap] = b.v;
+        }
+    }
+    __device__ __forceinline__ void store_any(uint32_t i, bool occluded) const {
+        vis[a_vidx[i - n_closest]] = occluded ? 1 : 0;
+    }
+};
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_slot_idx, uint32_t a_slot_idx,
+                                                            uint32_t head_idx, uint32_t chunk_hint) {
+    // queue lengths written by the previous stages (q_slot_idx / a_slot_idx = MISS: that queue is absent)
+    const uint32_t n_closest = q_slot_idx == MISS ? 0u : W.counts[q_slot_idx];
+    const uint32_t n_any = a_slot_idx == MISS ? 0u : W.counts[a_slot_idx];
+    const uint32_t n = n_closest + n_any;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        W.stats[0] += n_closest;
+        W.stats[1] += n_any;
+    }
+    if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;
+    const LdsMesh lds = stage_mesh_sched<USE_LDS>(S);
+    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_obj, W.h_prim, W.h_f, W.vis, W.cap, W.any_cap, n_closest};
+    // small queues: smaller chunks so that more waves share the work
+    uint32_t chunk = chunk_hint;
+    const uint32_t waves = gridDim.x * (TRACE_BLOCK / 64);
+    while (chunk > 64 && (n / chunk) < waves) chunk >>= 1;
+    trace_scheduler(S, lds, io, &W.counts[head_idx], n, chunk);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Stage 3: shade (integrate_recur after the hit, src/integrator.rs:66-102 with scatter_rays = 1).
-// Miss -> skybox, path ends.  Hit -> diffuse colour; if non-black, draw the light samples in light
-// order (their shadow rays go to the lit queue), then draw the scatter direction and append the
-// continuation ray to the next queue.  The per-pixel random stream is consumed in exactly the
-// order of the reference's recursion.
+// Miss -> skybox, path ends.  Hit -> rebuild the HitResult, diffuse colour; if non-black, draw the
+// light samples in light order (their shadow rays are appended to the any-hit queue one by one),
+// then draw the scatter direction and append the continuation ray to the next path queue.  The
+// per-pixel random stream is consumed in exactly the order of the reference's recursion.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint32_t cur, int32_t depth, int32_t max_depth, int32_t shadow_rays) {
-    const uint32_t n = W.counts[cur];
-    const float* r = W.q_ray[cur];
+__global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint32_t cur, int32_t depth, int32_t max_depth, int32_t shadow_rays,
+                                                    uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx) {
+    const uint32_t n = W.counts[q_in_idx];
+    const float* r = cur ? W.q_ray[1] : W.q_ray[0];
+    const uint32_t* q_slot_in = cur ? W.q_slot[1] : W.q_slot[0];
+    float* q_ray_out = cur ? W.q_ray[0] : W.q_ray[1];
+    uint32_t* q_slot_out = cur ? W.q_slot[0] : W.q_slot[1];
     const uint32_t cap = W.cap;
+    const size_t ac = W.any_cap;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_iter = (n + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; it++) {
@@ -375,17 +456,23 @@ __global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint
         f3 dir = mk(0, 0, 0), p = mk(0, 0, 0), p_out = mk(0, 0, 0), p_in = mk(0, 0, 0), nrm = mk(0, 0, 0);
         f3 diffuse = mk(0, 0, 0), beta = mk(1, 1, 1);
         if (active) {
-            slot = W.q_slot[cur][i];
+            slot = q_slot_in[i];
+            f3 pos = mk(r[i], r[i + cap], r[i + 2 * cap]);
             dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
             beta = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
-            mat = W.h_mat[i];
-            if (mat == MISS) {  // integrator.rs:66
+            Best b;
+            b.obj = W.h_obj[i];
+            if (b.obj == MISS) {  // integrator.rs:66
                 f3 c = beta * sky_color(S, dir);
                 W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
             } else {
                 hit = true;
-                f3 hp = mk(W.h_f[i + 2 * cap], W.h_f[i + 3 * cap], W.h_f[i + 4 * cap]);
-                f3 hn = mk(W.h_f[i + 5 * cap], W.h_f[i + 6 * cap], W.h_f[i + 7 * cap]);
+                b.prim = W.h_prim[i];
+                b.t_local = W.h_f[i]; b.u = W.h_f[i + cap]; b.v = W.h_f[i + 2 * cap];
+                f3 hp, hn;
+                float hu, hv;
+                reconstruct_hit(S, b, pos, dir, hp, hn, hu, hv);
+                mat = S.objects[b.obj].material;
                 nrm = normalize(hn);                                  // integrator.rs:72-76
                 bool outside = dot(nrm, -dir) > 0.0f;
                 p_out = hp + nrm * 0.001f;
@@ -395,32 +482,45 @@ __global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint
                 lit = !is_zero(diffuse);                               // integrator.rs:80
             }
         }
-        uint32_t lq = wave_append(lit, &W.counts[2]);
+        uint32_t lq = wave_append(lit, &W.counts[lit_idx]);
         // ---- phase B: draw light samples, then the scatter direction (same stream order) ----
         f3 next_pos = mk(0, 0, 0), next_dir = mk(0, 0, 0);
-        if (hit) {
-            Rng rng;
-            rng.lo = W.rng_lo[slot]; rng.hi = W.rng_hi[slot];
-            const DevMaterial m = S.materials[mat];
-            if (lit) {                                                 // integrator.rs:80-88
-                W.lit_slot[lq] = slot;
-                float* f = W.lit_f;
-                f[lq] = p.x; f[lq + cap] = p.y; f[lq + 2 * cap] = p.z;
-                f[lq + 3 * cap] = beta.x; f[lq + 4 * cap] = beta.y; f[lq + 5 * cap] = beta.z;
-                f[lq + 6 * cap] = diffuse.x; f[lq + 7 * cap] = diffuse.y; f[lq + 8 * cap] = diffuse.z;
-                uint32_t s = 0;
-                for (uint32_t l = 0; l < S.n_lights; l++) {
-                    const DevLight lt = S.lights[l];
-                    int ns = light_is_delta(lt) ? 1 : shadow_rays;
-                    for (int k = 0; k < ns; k++, s++) {
-                        f3 sd, ill; float tm;
+        Rng rng; rng.lo = 0; rng.hi = 0;
+        if (hit) { rng.lo = W.rng_lo[slot]; rng.hi = W.rng_hi[slot]; }
+        if (lit) {                                                     // integrator.rs:80-88
+            W.lit_slot[lq] = slot;
+            float* f = W.lit_f;
+            f[lq] = beta.x; f[lq + cap] = beta.y; f[lq + 2 * cap] = beta.z;
+            f[lq + 3 * cap] = diffuse.x; f[lq + 4 * cap] = diffuse.y; f[lq + 5 * cap] = diffuse.z;
+        }
+        {
+            uint32_t s = 0;
+            for (uint32_t l = 0; l < S.n_lights; l++) {
+                const DevLight lt = S.lights[l];
+                const int ns = light_is_delta(lt) ? 1 : shadow_rays;
+                for (int k = 0; k < ns; k++, s++) {
+                    bool shoot = false;
+                    f3 sd = mk(0, 0, 0), ill = mk(0, 0, 0);
+                    float tm = 0.0f;
+                    if (lit) {
                         light_sample(lt, nrm, rng, sd, tm, ill);
-                        float* q = W.smp + (size_t)s * 7 * cap + lq;
-                        q[0] = sd.x; q[cap] = sd.y; q[2 * (size_t)cap] = sd.z; q[3 * (size_t)cap] = tm;
-                        q[4 * (size_t)cap] = ill.x; q[5 * (size_t)cap] = ill.y; q[6 * (size_t)cap] = ill.z;
+                        float* q = W.smp + (size_t)s * 4 * cap + lq;
+                        q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z;
+                        shoot = !(tm == 0.0f);                         // integrator.rs:124
+                    }
+                    uint32_t aq = wave_append(shoot, &W.counts[any_idx]);
+                    if (shoot) {
+                        float* a = W.a_ray;
+                        a[aq] = p.x; a[aq + ac] = p.y; a[aq + 2 * ac] = p.z;
+                        a[aq + 3 * ac] = sd.x; a[aq + 4 * ac] = sd.y; a[aq + 5 * ac] = sd.z;
+                        a[aq + 6 * ac] = tm;
+                        W.a_vidx[aq] = s * cap + lq;
                     }
                 }
             }
+        }
+        if (hit) {
+            const DevMaterial m = S.materials[mat];
             f3 out, w;
             if (material_scatter(m, nrm, dir, rng, out, w)) {          // integrator.rs:90-101
                 f3 p2 = dot(out, nrm) > 0.0f ? p_out : p_in;
@@ -437,10 +537,10 @@ __global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint
             W.rng_lo[slot] = rng.lo; W.rng_hi[slot] = rng.hi;
         }
         // ---- compaction of the continuing paths into the next ray queue ----
-        uint32_t nq = wave_append(cont, &W.counts[cur ^ 1]);
+        uint32_t nq = wave_append(cont, &W.counts[q_out_idx]);
         if (cont) {
-            W.q_slot[cur ^ 1][nq] = slot;
-            float* o = W.q_ray[cur ^ 1];
+            q_slot_out[nq] = slot;
+            float* o = q_ray_out;
             o[nq] = next_pos.x; o[nq + cap] = next_pos.y; o[nq + 2 * cap] = next_pos.z;
             o[nq + 3 * cap] = next_dir.x; o[nq + 4 * cap] = next_dir.y; o[nq + 5 * cap] = next_dir.z;
         }
@@ -448,27 +548,23 @@ __global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint
 }
 
 // Marks every queued path as a miss (max_depth = 0: integrate_recur returns the skybox at once).
-__global__ void k_mark_miss(WaveBufs W) {
-    const uint32_t n = W.counts[0];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W.h_mat[i] = MISS;
+__global__ void k_mark_miss(WaveBufs W, uint32_t q_idx) {
+    const uint32_t n = W.counts[q_idx];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W.h_obj[i] = MISS;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 4: shadow rays of the lit queue (illumination(), src/integrator.rs:107-132) and the
-// `color += diffuse * illumination` of integrator.rs:87, weighted by the path throughput.
+// Stage 4: resolve the lit queue once its shadow rays are traced (illumination(),
+// src/integrator.rs:107-132) and add `diffuse * illumination` (integrator.rs:87), weighted by the
+// path throughput, to the sample's radiance.  Sums run in the reference's order.
 // ------------------------------------------------------------------------------------------------
-template <bool USE_LDS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_wave_shadow(DevScene S, WaveBufs W, int32_t shadow_rays) {
-    LdsMem mem;
-    const LdsMem* lm = stage_mesh<USE_LDS>(S, mem);
-    const uint32_t n = W.counts[2];
+__global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, int32_t shadow_rays, uint32_t lit_idx) {
+    const uint32_t n = W.counts[lit_idx];
     const uint32_t cap = W.cap;
-    uint32_t traced = 0;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         const float* f = W.lit_f;
-        f3 p = mk(f[j], f[j + cap], f[j + 2 * cap]);
-        f3 beta = mk(f[j + 3 * cap], f[j + 4 * cap], f[j + 5 * cap]);
-        f3 diffuse = mk(f[j + 6 * cap], f[j + 7 * cap], f[j + 8 * cap]);
+        f3 beta = mk(f[j], f[j + cap], f[j + 2 * cap]);
+        f3 diffuse = mk(f[j + 3 * cap], f[j + 4 * cap], f[j + 5 * cap]);
         f3 illum = fill(0.0f);
         uint32_t s = 0;
         for (uint32_t l = 0; l < S.n_lights; l++) {
@@ -476,15 +572,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_wave_shadow(DevScene S, WaveBuf
             int ns = light_is_delta(lt) ? 1 : shadow_rays;
             f3 total = fill(0.0f);
             for (int k = 0; k < ns; k++, s++) {
-                const float* q = W.smp + (size_t)s * 7 * cap + j;
-                f3 sd = mk(q[0], q[cap], q[2 * (size_t)cap]);
-                float tm = q[3 * (size_t)cap];
-                f3 ill = mk(q[4 * (size_t)cap], q[5 * (size_t)cap], q[6 * (size_t)cap]);
-                bool visible = true;
-                if (!(tm == 0.0f)) {                       // integrator.rs:124
-                    traced++;
-                    visible = !scene_any(S, lm, p, sd, tm);
-                }
+                const float* q = W.smp + (size_t)s * 4 * cap + j;
+                float tm = q[0];
+                f3 ill = mk(q[cap], q[2 * (size_t)cap], q[3 * (size_t)cap]);
+                bool visible = (tm == 0.0f) || (W.vis[(size_t)s * cap + j] == 0);   // integrator.rs:124
                 if (visible) total = total + ill;
             }
             illum = illum + total / (float)ns;             // integrator.rs:131, :84
@@ -493,9 +584,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_wave_shadow(DevScene S, WaveBuf
         uint32_t slot = W.lit_slot[j];
         W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
     }
-    // any-hit ray count: wave reduction, one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
-    if ((threadIdx.x & 63u) == 0 && traced) atomicAdd((unsigned long long*)&W.stats[1], (unsigned long long)traced);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,60 +622,92 @@ static inline uint32_t trace_grid(const LaunchCfg& cfg, size_t n) {
     return (uint32_t)(g ? g : 1);
 }
 
-hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, hipStream_t st) {
+static inline uint32_t sched_grid(const LaunchCfg& cfg, size_t upper) {
+    size_t need = (upper + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    size_t cap = (size_t)cfg.num_cus * cfg.sched_blocks_per_cu;
+    size_t g = need < cap ? need : cap;
+    return (uint32_t)(g ? g : 1);
+}
+static inline uint32_t sched_chunk(const LaunchCfg& cfg, size_t n, uint32_t grid) {
+    uint32_t chunk = (uint32_t)cfg.chunk;
+    const size_t waves = (size_t)grid * (TRACE_BLOCK / 64);
+    while (chunk > 64 && (n / chunk) < waves * 4) chunk >>= 1;
+    return chunk;
+}
+
+hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    const bool lds = cfg.use_lds && S.lds_mesh != MISS;
+    if (cfg.scheduler) {
+        hipError_t e = hipMemsetAsync(work_head, 0, 4, st);
+        if (e != hipSuccess) return e;
+        uint32_t g = sched_grid(cfg, n);
+        BatchIO io{S, rays, out, nullptr, false};
+        uint32_t chunk = sched_chunk(cfg, n, g);
+        if (lds) hipLaunchKernelGGL(k_trace_batch_sched<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, io, (uint32_t)n, work_head, chunk);
+        else hipLaunchKernelGGL(k_trace_batch_sched<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, io, (uint32_t)n, work_head, chunk);
+        return hipGetLastError();
+    }
     uint32_t g = trace_grid(cfg, n);
-    if (cfg.use_lds && S.lds_mesh != MISS)
-        hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, rays, out, (uint32_t)n);
-    else
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, rays, out, (uint32_t)n);
+    if (lds) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, rays, out, (uint32_t)n);
+    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, rays, out, (uint32_t)n);
     return hipGetLastError();
 }
-hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, uint8_t* out, size_t n, hipStream_t st) {
+hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, uint8_t* out, size_t n, uint32_t* work_head, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    const bool lds = cfg.use_lds && S.lds_mesh != MISS;
+    if (cfg.scheduler) {
+        hipError_t e = hipMemsetAsync(work_head, 0, 4, st);
+        if (e != hipSuccess) return e;
+        uint32_t g = sched_grid(cfg, n);
+        BatchIO io{S, rays, HitBatch{nullptr, nullptr, nullptr, nullptr, nullptr}, out, true};
+        uint32_t chunk = sched_chunk(cfg, n, g);
+        if (lds) hipLaunchKernelGGL(k_trace_batch_sched<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, io, (uint32_t)n, work_head, chunk);
+        else hipLaunchKernelGGL(k_trace_batch_sched<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, io, (uint32_t)n, work_head, chunk);
+        return hipGetLastError();
+    }
     uint32_t g = trace_grid(cfg, n);
-    if (cfg.use_lds && S.lds_mesh != MISS)
-        hipLaunchKernelGGL(k_trace_any<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, rays, out, (uint32_t)n);
-    else
-        hipLaunchKernelGGL(k_trace_any<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, rays, out, (uint32_t)n);
+    if (lds) hipLaunchKernelGGL(k_trace_any<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, rays, out, (uint32_t)n);
+    else hipLaunchKernelGGL(k_trace_any<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, rays, out, (uint32_t)n);
     return hipGetLastError();
 }
 hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
-                         uint32_t si, uint32_t sj, uint32_t aa, bool first, hipStream_t st) {
+                         uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t q_idx, hipStream_t st) {
     uint32_t g = (chunk_n + 255) / 256;
-    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(256), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, first ? 1u : 0u);
+    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(256), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, first ? 1u : 0u, q_idx);
     return hipGetLastError();
 }
-hipError_t launch_mark_miss(const WaveBufs& W, size_t upper, hipStream_t st) {
+hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st) {
     uint32_t g = (uint32_t)((upper + 255) / 256);
     if (g > 2048) g = 2048;
     if (!g) g = 1;
-    hipLaunchKernelGGL(k_mark_miss, dim3(g), dim3(256), 0, st, W);
+    hipLaunchKernelGGL(k_mark_miss, dim3(g), dim3(256), 0, st, W, q_idx);
     return hipGetLastError();
 }
-hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, size_t upper, hipStream_t st) {
-    uint32_t g = trace_grid(cfg, upper);
+hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
+                             uint32_t head_idx, size_t upper, hipStream_t st) {
+    uint32_t g = sched_grid(cfg, upper);
     if (cfg.use_lds && S.lds_mesh != MISS)
-        hipLaunchKernelGGL(k_wave_trace<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, W, cur);
+        hipLaunchKernelGGL(k_wave_trace<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk);
     else
-        hipLaunchKernelGGL(k_wave_trace<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, W, cur);
+        hipLaunchKernelGGL(k_wave_trace<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk);
     return hipGetLastError();
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
-                             int shadow_rays, size_t upper, hipStream_t st) {
+                             int shadow_rays, uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st) {
     size_t need = (upper + 255) / 256;
     size_t capg = (size_t)cfg.num_cus * 8;
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
-    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(256), 0, st, S, W, cur, depth, max_depth, shadow_rays);
+    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(256), 0, st, S, W, cur, depth, max_depth, shadow_rays, q_in, q_out, lit_idx, any_idx);
     return hipGetLastError();
 }
-hipError_t launch_wave_shadow(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, size_t upper, hipStream_t st) {
-    uint32_t g = trace_grid(cfg, upper);
-    if (cfg.use_lds && S.lds_mesh != MISS)
-        hipLaunchKernelGGL(k_wave_shadow<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, W, shadow_rays);
-    else
-        hipLaunchKernelGGL(k_wave_shadow<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, W, shadow_rays);
+hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, size_t upper, hipStream_t st) {
+    size_t need = (upper + 255) / 256;
+    size_t capg = (size_t)cfg.num_cus * 8;
+    uint32_t g = (uint32_t)(need < capg ? need : capg);
+    if (!g) g = 1;
+    hipLaunchKernelGGL(k_wave_resolve, dim3(g), dim3(256), 0, st, S, W, shadow_rays, lit_idx);
     return hipGetLastError();
 }
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out, hipStream_t st) {

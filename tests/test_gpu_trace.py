@@ -77,19 +77,22 @@ def test_any_hit_matches(rt, main_pair):
     assert 0 < ref.sum() < ref.size
 
 
-def test_lds_and_global_paths_agree(rt, main_pair):
+def test_kernel_variants_agree(rt, main_pair):
+    """LDS-staged vs L2-read mesh, persistent scheduler vs plain nested loops: all four give the same bits."""
     gpu, cpu, _ = main_pair
     rays = random_rays(100_000, seed=13)
-    gpu.set_option(rt.OPT_LDS_SCENE, 0)
-    a = gpu.trace_closest(rays)
-    sa = gpu.trace_any(rays)
-    gpu.set_option(rt.OPT_LDS_SCENE, 1)
-    b = gpu.trace_closest(rays)
-    sb = gpu.trace_any(rays)
-    for k in ("obj", "prim", "t", "u", "v"):
-        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
-    assert np.array_equal(sa, sb)
-    check_closest(rt, a, cpu.trace_closest(rays))
+    ref = cpu.trace_closest(rays)
+    ref_any, _ = cpu.trace_any(rays)
+    try:
+        for sched in (0, 1):
+            for lds in (0, 1):
+                gpu.set_option(rt.OPT_SCHEDULER, sched)
+                gpu.set_option(rt.OPT_LDS_SCENE, lds)
+                check_closest(rt, gpu.trace_closest(rays), ref)
+                assert np.array_equal(gpu.trace_any(rays), ref_any)
+    finally:
+        gpu.set_option(rt.OPT_SCHEDULER, 1)
+        gpu.set_option(rt.OPT_LDS_SCENE, 1)
 
 
 def test_axis_aligned_and_degenerate_rays(rt, main_pair):
