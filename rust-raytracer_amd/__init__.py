@@ -17,7 +17,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_RTAMD = os.path.join(PKG_DIR, "librtamd.so")
+LIB_RTAMD = os.environ.get("RTAMD_LIB", os.path.join(PKG_DIR, "librtamd.so"))  # RTAMD_LIB: diagnostic build override
 LIB_HOST = os.path.join(PKG_DIR, "librtamd_host.so")
 BUNNY_PLY = os.path.join(ROOT, "assets", "bunny.ply")
 SKYBOX_JPG = os.path.join(ROOT, "assets", "skybox.jpg")

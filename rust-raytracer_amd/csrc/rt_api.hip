@@ -366,6 +366,9 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         DevObject d{};
         d.geom_kind = ob.geom_kind; d.geom_index = ob.geom_index; d.material = ob.material;
         d.op_first = ob.op_first; d.op_count = ob.op_count;
+        if (ob.geom_kind == RTAMD_GEOM_MESH) {
+            d.node_base = meshes[ob.geom_index].node_base; d.n_nodes = meshes[ob.geom_index].n_nodes; d.tri_base = meshes[ob.geom_index].tri_base;
+        }
         objects.push_back(d);
     }
     std::vector<DevOp> ops;
@@ -449,6 +452,12 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     for (uint32_t m = 0; m < sc->n_meshes; m++) {
         size_t bytes = (size_t)meshes[m].n_nodes * 32 + (size_t)sc->meshes[m].n_tris * 48;
         if (bytes > 0 && bytes <= 52 * 1024) { S.lds_mesh = m; S.lds_bytes = (uint32_t)bytes; break; }
+    }
+    // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
+    S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
+    {
+        size_t tb = (size_t)sc->n_objects * 32 + (size_t)sc->n_ops * 48 + (size_t)sc->n_cuboids * 48 + (((size_t)sc->n_root * 8 + 15) & ~(size_t)15);
+        S.tab_bytes = tb <= 8192 ? (uint32_t)tb : 0u;
     }
     ctx->S = S;
     ctx->have_scene = true;
@@ -661,5 +670,16 @@ int rtamd_quantize_device(rtamd_context* ctx, const float* rgb, size_t n, uint8_
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RTAMD_OK;
 }
+
+#ifdef RTAMD_DIAG
+// Diagnostic build only: per-phase totals of the scheduler kernels (cycles, steps, active lanes) x 5 phases.
+int rtamd_diag_read(rtamd_context* ctx, unsigned long long out[32], int reset) {
+    if (!ctx) return RTAMD_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, rtamd::diag_read(out, reset));
+    return RTAMD_OK;
+}
+#endif
 
 }  // extern "C"

@@ -32,7 +32,8 @@ struct DevTree { uint32_t node_base, n_nodes, first_object, pad; };
 struct DevCuboid { float center[3], extent[3], inv_extent[3]; float pad[3]; };
 struct DevTriangle { float a[3], b[3], c[3]; float pad[3]; };
 struct DevOp { uint32_t kind; float v[9]; uint32_t pad[2]; };
-struct DevObject { uint32_t geom_kind, geom_index, material, op_first, op_count, pad[3]; };
+// mesh objects carry a copy of their mesh record, so entering an object is one 32-byte read
+struct DevObject { uint32_t geom_kind, geom_index, material, op_first, op_count, node_base, n_nodes, tri_base; };
 struct DevRootItem { uint32_t kind, index; };
 struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t pad[2]; };
 struct DevLight { uint32_t kind; float vec[3]; float param; float emission[3]; };
@@ -61,6 +62,8 @@ struct DevScene {
     uint32_t n_objects, n_meshes;
     uint32_t lds_mesh;        // mesh index staged in LDS by the trace kernels, or MISS
     uint32_t lds_bytes;       // bytes of LDS needed for that mesh
+    uint32_t n_ops, n_cuboids;
+    uint32_t tab_bytes;       // bytes of LDS for the scene tables (objects, ops, cuboids, root), 0 = keep them in global memory
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -243,11 +246,61 @@ __device__ __forceinline__ bool unit_cuboid_hit(f3 pos, f3 dir, float t_max, flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Scene tables (objects, wrapper ops, root list, cuboids) are read through an accessor so that the
+// traversal code is the same whether they sit in global memory or in an LDS copy.  Records are
+// fetched whole with 16-byte loads (one round trip per record instead of one per field).
+// ------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4f lds_float4;
+__device__ __forceinline__ float4 lds_load4(lds_float4* p) {
+    const v4f v = *p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+struct OpRec { uint32_t kind; float v[9]; };
+struct CuboidRec { f3 center, extent, inv_extent; };
+
+__device__ __forceinline__ DevObject unpack_object(float4 a, float4 b) {
+    DevObject o;
+    o.geom_kind = __float_as_uint(a.x); o.geom_index = __float_as_uint(a.y); o.material = __float_as_uint(a.z); o.op_first = __float_as_uint(a.w);
+    o.op_count = __float_as_uint(b.x); o.node_base = __float_as_uint(b.y); o.n_nodes = __float_as_uint(b.z); o.tri_base = __float_as_uint(b.w);
+    return o;
+}
+__device__ __forceinline__ OpRec unpack_op(float4 a, float4 b, float4 c) {
+    OpRec o;
+    o.kind = __float_as_uint(a.x);
+    o.v[0] = a.y; o.v[1] = a.z; o.v[2] = a.w; o.v[3] = b.x; o.v[4] = b.y; o.v[5] = b.z; o.v[6] = b.w; o.v[7] = c.x; o.v[8] = c.y;
+    return o;
+}
+__device__ __forceinline__ CuboidRec unpack_cuboid(float4 a, float4 b, float4 c) {
+    CuboidRec r;
+    r.center = mk(a.x, a.y, a.z); r.extent = mk(a.w, b.x, b.y); r.inv_extent = mk(b.z, b.w, c.x);
+    return r;
+}
+struct GlobalTab {
+    const DevScene* S;
+    __device__ __forceinline__ DevObject object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1]); }
+    __device__ __forceinline__ OpRec op(uint32_t i) const { const float4* p = (const float4*)(S->ops + i); return unpack_op(p[0], p[1], p[2]); }
+    __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { const float4* p = (const float4*)(S->cuboids + i); return unpack_cuboid(p[0], p[1], p[2]); }
+    __device__ __forceinline__ DevRootItem root(uint32_t i) const { return S->root[i]; }
+};
+struct LdsTab {
+    lds_float4* objects;  // 2 per object
+    lds_float4* ops;      // 3 per op
+    lds_float4* cuboids;  // 3 per cuboid
+    __attribute__((address_space(3))) const uint32_t* roots;  // kind, index pairs
+    __device__ __forceinline__ DevObject object(uint32_t i) const { return unpack_object(lds_load4(objects + 2 * i), lds_load4(objects + 2 * i + 1)); }
+    __device__ __forceinline__ OpRec op(uint32_t i) const { return unpack_op(lds_load4(ops + 3 * i), lds_load4(ops + 3 * i + 1), lds_load4(ops + 3 * i + 2)); }
+    __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { return unpack_cuboid(lds_load4(cuboids + 3 * i), lds_load4(cuboids + 3 * i + 1), lds_load4(cuboids + 3 * i + 2)); }
+    __device__ __forceinline__ DevRootItem root(uint32_t i) const { return DevRootItem{roots[2 * i], roots[2 * i + 1]}; }
+};
+
+// ------------------------------------------------------------------------------------------------
 // Ray-space wrappers going in (src/geom/transform.rs:57-58,104-106,178-180).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ops_in(const DevOp* __restrict__ ops, uint32_t first, uint32_t count, f3& pos, f3& dir, float& t_max) {
+template <class Tab>
+__device__ __forceinline__ void ops_in(const Tab& tab, uint32_t first, uint32_t count, f3& pos, f3& dir, float& t_max) {
     for (uint32_t k = 0; k < count; k++) {
-        const DevOp& op = ops[first + k];
+        const OpRec op = tab.op(first + k);
         if (op.kind == OP_TRANSLATE) {
             pos = pos - mk(op.v[0], op.v[1], op.v[2]);
         } else if (op.kind == OP_SCALE) {
@@ -260,17 +313,19 @@ __device__ __forceinline__ void ops_in(const DevOp* __restrict__ ops, uint32_t f
     }
 }
 // Hit distance coming back out: Scale multiplies t (transform.rs:107).
-__device__ __forceinline__ float ops_t_out(const DevOp* __restrict__ ops, uint32_t first, uint32_t count, float t) {
+template <class Tab>
+__device__ __forceinline__ float ops_t_out(const Tab& tab, uint32_t first, uint32_t count, float t) {
     for (uint32_t k = count; k-- > 0;) {
-        const DevOp& op = ops[first + k];
+        const OpRec op = tab.op(first + k);
         if (op.kind == OP_SCALE) t = t * op.v[0];
     }
     return t;
 }
 // Hit position / normal coming back out (transform.rs:61,108,183-184).
-__device__ __forceinline__ void ops_hit_out(const DevOp* __restrict__ ops, uint32_t first, uint32_t count, f3& pos, f3& nrm) {
+template <class Tab>
+__device__ __forceinline__ void ops_hit_out(const Tab& tab, uint32_t first, uint32_t count, f3& pos, f3& nrm) {
     for (uint32_t k = count; k-- > 0;) {
-        const DevOp& op = ops[first + k];
+        const OpRec op = tab.op(first + k);
         if (op.kind == OP_TRANSLATE) {
             pos = pos + mk(op.v[0], op.v[1], op.v[2]);
         } else if (op.kind == OP_SCALE) {
@@ -293,14 +348,14 @@ struct Best {
 // Closest-hit test of a non-mesh primitive in object space: UnitSphere::hit (sphere.rs:36-45),
 // Cuboid::hit -> UnitCuboid::hit (cuboid.rs:82-93,19-28), Triangle::hit (triangle.rs:41-44).
 // u, v are only produced for the triangle; sphere / cuboid uv come from reconstruct_hit().
-__device__ __forceinline__ bool primitive_closest(const DevScene& S, const DevObject& ob, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
+template <class Tab>
+__device__ __forceinline__ bool primitive_closest(const DevScene& S, const Tab& tab, const DevObject& ob, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
     if (ob.geom_kind == GEOM_UNIT_SPHERE) {
         return unit_sphere_hit(pos, dir, t_max, t);
     } else if (ob.geom_kind == GEOM_CUBOID) {
-        const DevCuboid c = S.cuboids[ob.geom_index];
-        f3 ie = mk(c.inv_extent[0], c.inv_extent[1], c.inv_extent[2]);
-        f3 p = (pos - mk(c.center[0], c.center[1], c.center[2])) * ie;  // cuboid.rs:83-85
-        f3 d = dir * ie;
+        const CuboidRec c = tab.cuboid(ob.geom_index);
+        f3 p = (pos - c.center) * c.inv_extent;  // cuboid.rs:83-85
+        f3 d = dir * c.inv_extent;
         return unit_cuboid_hit(p, d, t_max, t);
     } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {
         return unit_cuboid_hit(pos, dir, t_max, t);
@@ -315,12 +370,13 @@ __device__ __forceinline__ bool primitive_closest(const DevScene& S, const DevOb
 // Occlusion test of a non-mesh primitive: UnitSphere::is_hit (sphere.rs:63-69), Cuboid::is_hit
 // (cuboid.rs:95-100, world-space slab with Ray::inv_dir), UnitCuboid::is_hit (cuboid.rs:50-54),
 // Triangle::is_hit (triangle.rs:59-62).
-__device__ __forceinline__ bool primitive_any(const DevScene& S, const DevObject& ob, f3 pos, f3 dir, float t_max) {
+template <class Tab>
+__device__ __forceinline__ bool primitive_any(const DevScene& S, const Tab& tab, const DevObject& ob, f3 pos, f3 dir, float t_max) {
     if (ob.geom_kind == GEOM_UNIT_SPHERE) {
         return unit_sphere_any(pos, dir, t_max);
     } else if (ob.geom_kind == GEOM_CUBOID) {
-        const DevCuboid c = S.cuboids[ob.geom_index];
-        f3 ctr = mk(c.center[0], c.center[1], c.center[2]), ext = mk(c.extent[0], c.extent[1], c.extent[2]);
+        const CuboidRec c = tab.cuboid(ob.geom_index);
+        f3 ctr = c.center, ext = c.extent;
         f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         float t0, t1;
         box_roots(pos, inv, ctr - ext, ctr + ext, t0, t1);
@@ -344,9 +400,10 @@ __device__ __forceinline__ bool primitive_any(const DevScene& S, const DevObject
 // t_max (caller's space) when the object is hit within t_max.
 template <class Mem>
 __device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds_mem, uint32_t oi, f3 pos, f3 dir, float& t_max, Best& best) {
-    const DevObject ob = S.objects[oi];
+    const GlobalTab tab{&S};
+    const DevObject ob = tab.object(oi);
     float tl_max = t_max;
-    ops_in(S.ops, ob.op_first, ob.op_count, pos, dir, tl_max);
+    ops_in(tab, ob.op_first, ob.op_count, pos, dir, tl_max);
     float t = 0.0f, u = 0.0f, v = 0.0f;
     uint32_t prim = 0;
     bool hit = false;
@@ -360,11 +417,11 @@ __device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds
         }
         t = tl_max;
     } else {
-        hit = primitive_closest(S, ob, pos, dir, tl_max, t, u, v);
+        hit = primitive_closest(S, tab, ob, pos, dir, tl_max, t, u, v);
     }
     if (hit) {
         best.obj = oi; best.prim = prim; best.t_local = t; best.u = u; best.v = v;
-        t_max = ops_t_out(S.ops, ob.op_first, ob.op_count, t);
+        t_max = ops_t_out(tab, ob.op_first, ob.op_count, t);
     }
     return hit;
 }
@@ -372,8 +429,9 @@ __device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds
 // Object::is_hit (aggregate.rs:113-118) for the occlusion query.
 template <class Mem>
 __device__ __forceinline__ bool object_any(const DevScene& S, const Mem* lds_mem, uint32_t oi, f3 pos, f3 dir, float t_max) {
-    const DevObject ob = S.objects[oi];
-    ops_in(S.ops, ob.op_first, ob.op_count, pos, dir, t_max);
+    const GlobalTab tab{&S};
+    const DevObject ob = tab.object(oi);
+    ops_in(tab, ob.op_first, ob.op_count, pos, dir, t_max);
     if (ob.geom_kind == GEOM_MESH) {
         const DevMesh m = S.meshes[ob.geom_index];
         uint32_t prim; float u, v;
@@ -383,7 +441,7 @@ __device__ __forceinline__ bool object_any(const DevScene& S, const Mem* lds_mem
         GlobalMem gm{S.nodes + 2 * (size_t)m.node_base, S.tris + 3 * (size_t)m.tri_base};
         return traverse_mesh<true>(gm, m.n_nodes, pos, dir, t_max, prim, u, v);
     }
-    return primitive_any(S, ob, pos, dir, t_max);
+    return primitive_any(S, tab, ob, pos, dir, t_max);
 }
 
 // GeometryList::hit (src/geom/aggregate.rs:24-35) over the root items; an object tree item is
@@ -458,9 +516,10 @@ __device__ __forceinline__ bool scene_any(const DevScene& S, const Mem* lds_mem,
 // on the way out).  Needs the original ray; recomputes the object-space ray with the same
 // operations as the traversal did.
 __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b, f3 pos, f3 dir, f3& hpos, f3& hnorm, float& hu, float& hv) {
-    const DevObject ob = S.objects[b.obj];
+    const GlobalTab tab{&S};
+    const DevObject ob = tab.object(b.obj);
     float dummy = 0.0f;
-    ops_in(S.ops, ob.op_first, ob.op_count, pos, dir, dummy);
+    ops_in(tab, ob.op_first, ob.op_count, pos, dir, dummy);
     f3 p, n;
     hu = b.u; hv = b.v;
     if (ob.geom_kind == GEOM_MESH) {
@@ -479,12 +538,12 @@ __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b
         hv = acosf(n.z) / PI_F;
     } else if (ob.geom_kind == GEOM_CUBOID || ob.geom_kind == GEOM_UNIT_CUBOID) {
         f3 lp = pos, ld = dir;
-        DevCuboid c;
+        CuboidRec c;
+        c.center = mk(0, 0, 0); c.extent = mk(1, 1, 1); c.inv_extent = mk(1, 1, 1);
         if (ob.geom_kind == GEOM_CUBOID) {
-            c = S.cuboids[ob.geom_index];
-            f3 ie = mk(c.inv_extent[0], c.inv_extent[1], c.inv_extent[2]);
-            lp = (pos - mk(c.center[0], c.center[1], c.center[2])) * ie;
-            ld = dir * ie;
+            c = tab.cuboid(ob.geom_index);
+            lp = (pos - c.center) * c.inv_extent;
+            ld = dir * c.inv_extent;
         }
         f3 q = lp + fill(b.t_local) * ld;
         f3 qa = mk(fabsf(q.x), fabsf(q.y), fabsf(q.z));
@@ -492,15 +551,14 @@ __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b
         else if (qa.y > qa.z) { n = mk(0.0f, q.y, 0.0f); hu = q.x; hv = q.z; }
         else { n = mk(0.0f, 0.0f, q.z); hu = q.x; hv = q.y; }
         p = q;
-        if (ob.geom_kind == GEOM_CUBOID)
-            p = q * mk(c.extent[0], c.extent[1], c.extent[2]) + mk(c.center[0], c.center[1], c.center[2]);
+        if (ob.geom_kind == GEOM_CUBOID) p = q * c.extent + c.center;
     } else {
         const DevTriangle tr = S.triangles[ob.geom_index];
         f3 a = mk(tr.a[0], tr.a[1], tr.a[2]);
         n = cross(mk(tr.b[0], tr.b[1], tr.b[2]) - a, mk(tr.c[0], tr.c[1], tr.c[2]) - a);
         p = pos + fill(b.t_local) * dir;
     }
-    ops_hit_out(S.ops, ob.op_first, ob.op_count, p, n);
+    ops_hit_out(tab, ob.op_first, ob.op_count, p, n);
     hpos = p; hnorm = n;
 }
 

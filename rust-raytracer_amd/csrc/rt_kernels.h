@@ -5,6 +5,10 @@
 namespace rtamd {
 
 static constexpr int TRACE_BLOCK = 512;  // threads per block of the traversal kernels (8 waves)
+#ifndef RTAMD_SCHED_WAVES
+#define RTAMD_SCHED_WAVES 5
+#endif
+static constexpr int SCHED_WAVES_PER_SIMD = RTAMD_SCHED_WAVES;  // register budget of the scheduler kernels (6 waves/SIMD spills and is slower)
 
 struct RayBatch { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };
 struct HitBatch { uint32_t *obj, *prim; float *t, *u, *v; };
@@ -62,7 +66,7 @@ struct CounterSlots {
 struct LaunchCfg {
     int num_cus = 256;
     int trace_blocks_per_cu = 4;   // grid-stride kernels
-    int sched_blocks_per_cu = 2;   // persistent scheduler kernels (512 threads each)
+    int sched_blocks_per_cu = 3;   // persistent scheduler kernels (512 threads each)
     int chunk = 256;               // rays a wave dequeues per atomic
     int use_lds = 1;
     int scheduler = 1;             // 1: persistent phase-voting scheduler, 0: plain nested-loop kernels (batch entry points only)
@@ -80,5 +84,8 @@ hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const Wave
 hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, size_t upper, hipStream_t st);
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
+#ifdef RTAMD_DIAG
+hipError_t diag_read(unsigned long long* out, int reset);
+#endif
 
 }  // namespace rtamd

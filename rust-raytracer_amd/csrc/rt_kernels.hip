@@ -80,15 +80,41 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene S, RayBatch 
 }
 
 // Scheduler versions of the two batch kernels (see rt_sched.h).
-template <bool USE_LDS>
-__device__ __forceinline__ LdsMesh stage_mesh_sched(const DevScene& S) {
-    LdsMesh l{nullptr, nullptr};
-    if (USE_LDS) {
-        LdsMem mem;
-        stage_mesh<true>(S, mem);
-        l.nodes = mem.nodes; l.tris = mem.tris;
+// Stages the LDS-resident parts of the scene for a scheduler kernel: the small mesh (MESHLOC != GLOBAL)
+// followed by the scene tables (TAB_LDS).  LDS layout, in float4 units:
+//   [mesh nodes | mesh triangles | objects (2 each) | ops (3 each) | cuboids (3 each) | root items (uint2)]
+template <int MESHLOC, bool TAB_LDS>
+__device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, LdsTab& ltab) {
+    uint32_t base = 0;  // float4 offset
+    lds.nodes = (lds_float4*)g_lds;
+    lds.tris = (lds_float4*)g_lds;
+    if (MESHLOC != MESH_GLOBAL) {
+        const DevMesh m = S.meshes[S.lds_mesh];
+        const uint32_t n_node4 = 2 * m.n_nodes;
+        const uint32_t n_mesh4 = S.lds_bytes / 16;
+        const float4* gn = S.nodes + 2 * (size_t)m.node_base;
+        const float4* gt = S.tris + 3 * (size_t)m.tri_base;
+        for (uint32_t i = threadIdx.x; i < n_node4; i += blockDim.x) g_lds[i] = gn[i];
+        for (uint32_t i = threadIdx.x; i < n_mesh4 - n_node4; i += blockDim.x) g_lds[n_node4 + i] = gt[i];
+        lds.tris = (lds_float4*)g_lds + n_node4;
+        base = n_mesh4;
     }
-    return l;
+    if (TAB_LDS) {
+        const uint32_t n_obj4 = 2 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
+        const float4* go = (const float4*)S.objects;
+        const float4* gp = (const float4*)S.ops;
+        const float4* gc = (const float4*)S.cuboids;
+        for (uint32_t i = threadIdx.x; i < n_obj4; i += blockDim.x) g_lds[base + i] = go[i];
+        for (uint32_t i = threadIdx.x; i < n_op4; i += blockDim.x) g_lds[base + n_obj4 + i] = gp[i];
+        for (uint32_t i = threadIdx.x; i < n_cub4; i += blockDim.x) g_lds[base + n_obj4 + n_op4 + i] = gc[i];
+        uint2* lr = (uint2*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
+        for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
+        ltab.objects = (lds_float4*)g_lds + base;
+        ltab.ops = (lds_float4*)g_lds + base + n_obj4;
+        ltab.cuboids = (lds_float4*)g_lds + base + n_obj4 + n_op4;
+        ltab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
+    }
+    if (MESHLOC != MESH_GLOBAL || TAB_LDS) __syncthreads();
 }
 
 struct BatchIO {
@@ -97,13 +123,14 @@ struct BatchIO {
     HitBatch hits;
     uint8_t* any_out;
     bool any_mode;
-    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any) const {
+    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
         pos = mk(rays.ox[i], rays.oy[i], rays.oz[i]);
         dir = mk(rays.dx[i], rays.dy[i], rays.dz[i]);
         tmax = rays.tmax[i];
         any = any_mode;
+        tag = 0;
     }
-    __device__ __forceinline__ void store_closest(uint32_t i, bool found, const Best& b, float t_world) const {
+    __device__ __forceinline__ void store_closest(uint32_t i, uint32_t, bool found, const Best& b, float t_world) const {
         float hu = b.u, hv = b.v;
         if (found && S.objects[b.obj].geom_kind != GEOM_MESH && S.objects[b.obj].geom_kind != GEOM_TRIANGLE) {
             f3 hp, hn;  // sphere / cuboid uv need the hit point
@@ -115,14 +142,17 @@ struct BatchIO {
         hits.u[i] = found ? hu : 0.0f;
         hits.v[i] = found ? hv : 0.0f;
     }
-    __device__ __forceinline__ void store_any(uint32_t i, bool occluded) const { any_out[i] = occluded ? 1 : 0; }
+    __device__ __forceinline__ void store_any(uint32_t i, uint32_t, bool occluded) const { any_out[i] = occluded ? 1 : 0; }
 };
 
-template <bool USE_LDS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
+template <int MESHLOC, bool TAB_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
     if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;  // enough earlier blocks exist to cover the batch
-    const LdsMesh lds = stage_mesh_sched<USE_LDS>(S);
-    trace_scheduler(S, lds, io, work_head, n, chunk);
+    LdsMesh lds;
+    LdsTab ltab;
+    stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,13 +409,14 @@ struct WaveIO {
     uint8_t* vis;
     uint32_t cap, any_cap;
     uint32_t n_closest;
-    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any) const {
+    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
         if (i < n_closest) {
             const float* r = q_ray;
             pos = mk(r[i], r[i + cap], r[i + 2 * cap]);
             dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
             tmax = 1e12f;
             any = false;
+            tag = 0;
         } else {
             const uint32_t j = i - n_closest;
             const size_t ac = any_cap;
@@ -394,22 +425,21 @@ struct WaveIO {
             dir = mk(r[j + 3 * ac], r[j + 4 * ac], r[j + 5 * ac]);
             tmax = r[j + 6 * ac];
             any = true;
+            tag = a_vidx[j];
         }
     }
-    __device__ __forceinline__ void store_closest(uint32_t i, bool found, const Best& b, float) const {
+    __device__ __forceinline__ void store_closest(uint32_t i, uint32_t, bool found, const Best& b, float) const {
         h_obj[i] = found ? b.obj : MISS;
         if (found) {
             h_prim[i] = b.prim;
             h_f[i] = b.t_local; h_f[i + cap] = b.u; h_f[i + 2 * cap] = b.v;
         }
     }
-    __device__ __forceinline__ void store_any(uint32_t i, bool occluded) const {
-        vis[a_vidx[i - n_closest]] = occluded ? 1 : 0;
-    }
+    __device__ __forceinline__ void store_any(uint32_t, uint32_t tag, bool occluded) const { vis[tag] = occluded ? 1 : 0; }
 };
 
-template <bool USE_LDS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_slot_idx, uint32_t a_slot_idx,
+template <int MESHLOC, bool TAB_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_slot_idx, uint32_t a_slot_idx,
                                                             uint32_t head_idx, uint32_t chunk_hint) {
     // queue lengths written by the previous stages (q_slot_idx / a_slot_idx = MISS: that queue is absent)
     const uint32_t n_closest = q_slot_idx == MISS ? 0u : W.counts[q_slot_idx];
@@ -420,13 +450,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_wave_trace(DevScene S, WaveBufs
         W.stats[1] += n_any;
     }
     if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;
-    const LdsMesh lds = stage_mesh_sched<USE_LDS>(S);
+    LdsMesh lds;
+    LdsTab ltab;
+    stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
     WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_obj, W.h_prim, W.h_f, W.vis, W.cap, W.any_cap, n_closest};
     // small queues: smaller chunks so that more waves share the work
     uint32_t chunk = chunk_hint;
     const uint32_t waves = gridDim.x * (TRACE_BLOCK / 64);
     while (chunk > 64 && (n / chunk) < waves) chunk >>= 1;
-    trace_scheduler(S, lds, io, &W.counts[head_idx], n, chunk);
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,6 +661,26 @@ static inline uint32_t sched_grid(const LaunchCfg& cfg, size_t upper) {
     size_t g = need < cap ? need : cap;
     return (uint32_t)(g ? g : 1);
 }
+// Which template instance a launch needs: all mesh trees staged in LDS, none, or a mix.
+static inline int mesh_location(const DevScene& S, const LaunchCfg& cfg) {
+    if (!cfg.use_lds || S.lds_mesh == MISS) return MESH_GLOBAL;
+    return S.n_meshes == 1 ? MESH_LDS : MESH_MIXED;
+}
+#define RTAMD_DISPATCH_TAB(KERNEL, ML, tab, grid, lds_bytes, st, ...)                                                          \
+    do {                                                                                                                    \
+        if (tab) hipLaunchKernelGGL((KERNEL<ML, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);           \
+        else hipLaunchKernelGGL((KERNEL<ML, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);              \
+    } while (0)
+#define RTAMD_DISPATCH_MESHLOC(S, cfg, KERNEL, grid, st, ...)                                                                 \
+    do {                                                                                                                    \
+        const int loc_ = mesh_location(S, cfg);                                                                             \
+        const bool tab_ = cfg.use_lds && (S).tab_bytes > 0;                                                                  \
+        const uint32_t lb_ = (loc_ != MESH_GLOBAL ? (S).lds_bytes : 0u) + (tab_ ? (S).tab_bytes : 0u);                        \
+        if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, grid, lb_, st, __VA_ARGS__);                         \
+        else if (loc_ == MESH_MIXED) RTAMD_DISPATCH_TAB(KERNEL, MESH_MIXED, tab_, grid, lb_, st, __VA_ARGS__);                \
+        else RTAMD_DISPATCH_TAB(KERNEL, MESH_GLOBAL, tab_, grid, lb_, st, __VA_ARGS__);                                       \
+    } while (0)
+
 static inline uint32_t sched_chunk(const LaunchCfg& cfg, size_t n, uint32_t grid) {
     uint32_t chunk = (uint32_t)cfg.chunk;
     const size_t waves = (size_t)grid * (TRACE_BLOCK / 64);
@@ -644,8 +697,7 @@ hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const R
         uint32_t g = sched_grid(cfg, n);
         BatchIO io{S, rays, out, nullptr, false};
         uint32_t chunk = sched_chunk(cfg, n, g);
-        if (lds) hipLaunchKernelGGL(k_trace_batch_sched<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, io, (uint32_t)n, work_head, chunk);
-        else hipLaunchKernelGGL(k_trace_batch_sched<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, io, (uint32_t)n, work_head, chunk);
+        RTAMD_DISPATCH_MESHLOC(S, cfg, k_trace_batch_sched, g, st, S, io, (uint32_t)n, work_head, chunk);
         return hipGetLastError();
     }
     uint32_t g = trace_grid(cfg, n);
@@ -662,8 +714,7 @@ hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBa
         uint32_t g = sched_grid(cfg, n);
         BatchIO io{S, rays, HitBatch{nullptr, nullptr, nullptr, nullptr, nullptr}, out, true};
         uint32_t chunk = sched_chunk(cfg, n, g);
-        if (lds) hipLaunchKernelGGL(k_trace_batch_sched<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, io, (uint32_t)n, work_head, chunk);
-        else hipLaunchKernelGGL(k_trace_batch_sched<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, io, (uint32_t)n, work_head, chunk);
+        RTAMD_DISPATCH_MESHLOC(S, cfg, k_trace_batch_sched, g, st, S, io, (uint32_t)n, work_head, chunk);
         return hipGetLastError();
     }
     uint32_t g = trace_grid(cfg, n);
@@ -687,10 +738,7 @@ hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hip
 hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
                              uint32_t head_idx, size_t upper, hipStream_t st) {
     uint32_t g = sched_grid(cfg, upper);
-    if (cfg.use_lds && S.lds_mesh != MISS)
-        hipLaunchKernelGGL(k_wave_trace<true>, dim3(g), dim3(TRACE_BLOCK), S.lds_bytes, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk);
-    else
-        hipLaunchKernelGGL(k_wave_trace<false>, dim3(g), dim3(TRACE_BLOCK), 0, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk);
+    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk);
     return hipGetLastError();
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
@@ -721,5 +769,17 @@ hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t
     hipLaunchKernelGGL(k_quantize, dim3(g), dim3(256), 0, st, rgb, n, out);
     return hipGetLastError();
 }
+
+#ifdef RTAMD_DIAG
+hipError_t diag_read(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), 256);
+    if (e != hipSuccess) return e;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, 256);
+    }
+    return e;
+}
+#endif
 
 }  // namespace rtamd

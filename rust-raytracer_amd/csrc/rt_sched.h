@@ -8,7 +8,7 @@
 // over the SAME per-ray operation sequence as the reference (so results stay bit-identical), and
 // each trip of the wave's loop executes the one phase that the most lanes are waiting for:
 //
-//   FETCH  store the finished ray's result, take the next ray index (wave-aggregated dequeue)
+//   FETCH  store the finished ray's result, start on the prefetched next ray, prefetch another
 //   OBJ    fold a finished mesh walk, step the root list / object-tree leaf, enter the next object
 //          (ray-space wrappers, 1/dir) or intersect a non-mesh primitive
 //   TNODE  one node of an object tree (world space)
@@ -24,29 +24,87 @@ namespace rtamd {
 
 enum : uint32_t { ST_FETCH = 0, ST_OBJ = 1, ST_TNODE = 2, ST_NODE = 3, ST_TRI = 4, ST_DONE = 5 };
 
+// LDS copy of mesh S.lds_mesh, addressed through LDS-typed pointers so that the loads are
+// ds_read_b128 (a generic pointer that may be LDS or global compiles to slow flat loads).
 struct LdsMesh {
-    const float4* nodes;  // LDS copy of mesh S.lds_mesh (nullptr when nothing is staged)
-    const float4* tris;
+    lds_float4* nodes;
+    lds_float4* tris;
 };
+// Where the mesh trees of a launch live: decided on the host per scene.
+enum : int { MESH_GLOBAL = 0, MESH_LDS = 1, MESH_MIXED = 2 };
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
+
+// Diagnostic build only (-DRTAMD_DIAG): per-phase cycle, step and active-lane totals of the scheduler,
+// accumulated per wave and added to a global table when the wave ends.  Never compiled into librtamd.so.
+#ifdef RTAMD_DIAG
+__device__ unsigned long long g_diag[32];
+#define DIAG_DECL unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_steps[6] = {0, 0, 0, 0, 0, 0}, d_lanes[6] = {0, 0, 0, 0, 0, 0}; unsigned long long d_t0 = 0;
+#define DIAG_TOP d_t0 = __builtin_amdgcn_s_memtime();
+#define DIAG_STEP(ph, c) { d_steps[ph] += 1; d_lanes[ph] += (c); }
+#define DIAG_END(ph) { d_cyc[ph] += __builtin_amdgcn_s_memtime() - d_t0; }
+#define DIAG_FLUSH if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
+#else
+#define DIAG_DECL
+#define DIAG_TOP
+#define DIAG_STEP(ph, c)
+#define DIAG_END(ph)
+#define DIAG_FLUSH
+#endif
+
+// Wave-aggregated dequeue: lanes with `want` receive consecutive ray indices (MISS when the queue
+// is empty).  chunk_next / chunk_end / exhausted are wave-uniform; must be called in uniform flow.
+__device__ __forceinline__ uint32_t wave_dequeue(bool want, uint32_t lane, unsigned long long lt_mask, uint32_t* work_head, uint32_t n_items,
+                                                 uint32_t chunk, uint32_t& chunk_next, uint32_t& chunk_end, bool& exhausted) {
+    const unsigned long long need = __ballot(want);
+    if (need == 0ull) return MISS;
+    const uint32_t cnt = __popcll(need), rank = __popcll(need & lt_mask);
+    uint32_t avail = chunk_end - chunk_next;
+    const uint32_t taken = cnt < avail ? cnt : avail;
+    uint32_t my = MISS;
+    if (want && rank < taken) my = chunk_next + rank;
+    chunk_next += taken;
+    if (taken < cnt && !exhausted) {  // one refill is enough: chunk >= 64
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(work_head, chunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n_items) { exhausted = true; base = n_items; }
+        chunk_next = base;
+        chunk_end = (n_items - base) < chunk ? n_items : base + chunk;
+        avail = chunk_end - chunk_next;
+        const uint32_t rest = cnt - taken;
+        const uint32_t taken2 = rest < avail ? rest : avail;
+        if (want && rank >= taken && (rank - taken) < taken2) my = chunk_next + (rank - taken);
+        chunk_next += taken2;
+    }
+    return my;
+}
+
 // IO concept:
-//   void load(uint32_t idx, f3& pos, f3& dir, float& tmax, bool& any) const;
-//   void store_closest(uint32_t idx, bool found, const Best& b, float t_world) const;
-//   void store_any(uint32_t idx, bool occluded) const;
-template <class IO>
-__device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh lds, const IO& io, uint32_t* work_head,
+//   void load(uint32_t idx, f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const;
+//   void store_closest(uint32_t idx, uint32_t tag, bool found, const Best& b, float t_world) const;
+//   void store_any(uint32_t idx, uint32_t tag, bool occluded) const;
+// `tag` is an opaque word the IO wants back when the result is stored (loaded with the ray, so that
+// storing never needs a dependent read).
+template <int MESHLOC, class Tab, class IO>
+__device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
                                                 const uint32_t n_items, const uint32_t chunk) {
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
     uint32_t st = ST_FETCH;
     bool have = false, any = false, occluded = false;
-    uint32_t ridx = 0;
+    uint32_t ridx = 0, rtag = 0;
     f3 wpos = mk(0, 0, 0), wdir = mk(0, 0, 1), winv = mk(0, 0, 0);
     bool wngx = false, wngy = false, wngz = false;
     float wtmax = 0.0f;
+    // prefetched next ray of this lane (its loads are issued one ray ahead of use)
+    uint32_t nx_idx = MISS, nx_tag = 0;
+    f3 nx_pos = mk(0, 0, 0), nx_dir = mk(0, 0, 1);
+    float nx_tmax = 0.0f;
+    bool nx_any = false;
     Best best;
     best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
     uint32_t root_i = 0;
@@ -64,7 +122,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool exhausted = false;                   // wave-uniform: the global queue has run dry
 
+    DIAG_DECL
     for (;;) {
+        DIAG_TOP
         // ---- vote: run the phase most lanes are waiting for ----
         const uint32_t c_tri = __popcll(__ballot(st == ST_TRI));
         const uint32_t c_node = __popcll(__ballot(st == ST_NODE));
@@ -79,10 +139,19 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
         if (c_fetch > top) { top = c_fetch; phase = ST_FETCH; }
 
         if (phase == ST_TRI) {
+          // stay in the phase while at least STAY_NUM/STAY_DEN of the lanes that entered it still need it:
+          // one ballot per step instead of a full vote
+          for (uint32_t c = c_tri; c * STAY_DEN >= c_tri * STAY_NUM && c > 0; c = __popcll(__ballot(st == ST_TRI))) {
+            DIAG_STEP(ST_TRI, c)
             if (st == ST_TRI) {
                 float4 q0, q1, q2;
-                if (mesh_lds) { q0 = lds.tris[3 * k_cur]; q1 = lds.tris[3 * k_cur + 1]; q2 = lds.tris[3 * k_cur + 2]; }
-                else { const float4* tp = S.tris + 3 * ((size_t)tri_off + k_cur); q0 = tp[0]; q1 = tp[1]; q2 = tp[2]; }
+                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && mesh_lds)) {
+                    lds_float4* tp = lds.tris + 3 * k_cur;
+                    q0 = lds_load4(tp); q1 = lds_load4(tp + 1); q2 = lds_load4(tp + 2);
+                } else {
+                    const float4* tp = S.tris + 3 * ((size_t)tri_off + k_cur);
+                    q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
+                }
                 float t, u, v;
                 if (tri_test(q0, q1, q2, opos, odir, otmax, t, u, v)) {
                     if (any) { occluded = true; have = true; st = ST_FETCH; }
@@ -94,11 +163,19 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                     if (n_i >= n_n) { mesh_pending = true; st = ST_OBJ; } else st = ST_NODE;
                 }
             }
+          }
         } else if (phase == ST_NODE) {
+          for (uint32_t c = c_node; c * STAY_DEN >= c_node * STAY_NUM && c > 0; c = __popcll(__ballot(st == ST_NODE))) {
+            DIAG_STEP(ST_NODE, c)
             if (st == ST_NODE) {
                 float4 n0, n1;
-                if (mesh_lds) { n0 = lds.nodes[2 * n_i]; n1 = lds.nodes[2 * n_i + 1]; }
-                else { const float4* np = S.nodes + 2 * ((size_t)node_off + n_i); n0 = np[0]; n1 = np[1]; }
+                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && mesh_lds)) {
+                    lds_float4* np = lds.nodes + 2 * n_i;
+                    n0 = lds_load4(np); n1 = lds_load4(np + 1);
+                } else {
+                    const float4* np = S.nodes + 2 * ((size_t)node_off + n_i);
+                    n0 = np[0]; n1 = np[1];
+                }
                 const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
                 const bool leaf = (A & LEAF_BIT) != 0u;
                 if (node_passes(n0, n1, opos, oinv, ongx, ongy, ongz, otmax)) {
@@ -109,7 +186,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                 }
                 if (st == ST_NODE && n_i >= n_n) { mesh_pending = true; st = ST_OBJ; }
             }
+          }
         } else if (phase == ST_TNODE) {
+          for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * STAY_NUM && c > 0; c = __popcll(__ballot(st == ST_TNODE))) {
+            DIAG_STEP(ST_TNODE, c)
             if (st == ST_TNODE) {
                 const float4* np = S.nodes + 2 * ((size_t)t_base + t_i);
                 float4 n0 = np[0], n1 = np[1];
@@ -123,14 +203,16 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                 }
                 if (st == ST_TNODE && t_i >= t_n) { in_tree = false; st = ST_OBJ; }
             }
+          }
         } else if (phase == ST_OBJ) {
+            DIAG_STEP(ST_OBJ, c_obj)
             if (st == ST_OBJ) {
                 // (1) fold a finished mesh walk into the ray's closest hit (bvh.rs:262-264, transform.rs:107)
                 if (mesh_pending) {
                     mesh_pending = false;
                     if (ofound) {
                         best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
-                        wtmax = ops_t_out(S.ops, op_first, op_count, otmax);
+                        wtmax = ops_t_out(tab, op_first, op_count, otmax);
                     }
                 }
                 // (2) where does the next object come from?
@@ -143,7 +225,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                         if (root_i >= S.n_root) {
                             have = true; st = ST_FETCH;  // GeometryList exhausted: the ray is finished
                         } else {
-                            const DevRootItem it = S.root[root_i++];
+                            const DevRootItem it = tab.root(root_i++);
                             if (it.kind == ROOT_OBJECT) { o_cur = it.index; o_end = it.index + 1; }
                             else {
                                 const DevTree tr = S.trees[it.index];
@@ -158,14 +240,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                 // (3) enter the next object
                 if (st == ST_OBJ && o_cur < o_end) {
                     oi = o_cur++;
-                    const DevObject ob = S.objects[oi];
+                    const DevObject ob = tab.object(oi);
                     op_first = ob.op_first; op_count = ob.op_count;
                     opos = wpos; odir = wdir; otmax = wtmax;
-                    ops_in(S.ops, op_first, op_count, opos, odir, otmax);
+                    ops_in(tab, op_first, op_count, opos, odir, otmax);
                     if (ob.geom_kind == GEOM_MESH) {
-                        const DevMesh m = S.meshes[ob.geom_index];
-                        n_n = m.n_nodes; n_i = 0; node_off = m.node_base; tri_off = m.tri_base;
-                        mesh_lds = (lds.nodes != nullptr) && (ob.geom_index == S.lds_mesh);
+                        n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
+                        mesh_lds = (MESHLOC != MESH_GLOBAL) && (ob.geom_index == S.lds_mesh);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
                         ongx = signbit32(oinv.x); ongy = signbit32(oinv.y); ongz = signbit32(oinv.z);
                         ofound = false;
@@ -174,13 +255,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                         float t = 0.0f;
                         bool hit;
                         if (any) {
-                            hit = primitive_any(S, ob, opos, odir, otmax);
+                            hit = primitive_any(S, tab, ob, opos, odir, otmax);
                         } else {
                             float u = 0.f, v = 0.f;
-                            hit = primitive_closest(S, ob, opos, odir, otmax, t, u, v);
+                            hit = primitive_closest(S, tab, ob, opos, odir, otmax, t, u, v);
                             if (hit) {
                                 best.obj = oi; best.prim = 0; best.t_local = t; best.u = u; best.v = v;
-                                wtmax = ops_t_out(S.ops, op_first, op_count, t);
+                                wtmax = ops_t_out(tab, op_first, op_count, t);
                             }
                         }
                         if (any && hit) { occluded = true; have = true; st = ST_FETCH; }
@@ -188,37 +269,34 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                 }
             }
         } else {  // ST_FETCH
+            DIAG_STEP(ST_FETCH, c_fetch)
             const bool want = st == ST_FETCH;
             if (want && have) {
                 have = false;
-                if (any) io.store_any(ridx, occluded);
-                else io.store_closest(ridx, best.obj != MISS, best, wtmax);
+                if (any) io.store_any(ridx, rtag, occluded);
+                else io.store_closest(ridx, rtag, best.obj != MISS, best, wtmax);
             }
-            // wave-aggregated dequeue from the wave's chunk; one refill at most (chunk >= 64)
-            const unsigned long long need = __ballot(want);
-            const uint32_t cnt = __popcll(need), rank = __popcll(need & lt_mask);
-            uint32_t avail = chunk_end - chunk_next;
-            const uint32_t taken = cnt < avail ? cnt : avail;
-            uint32_t my = MISS;
-            if (want && rank < taken) my = chunk_next + rank;
-            chunk_next += taken;
-            if (taken < cnt && !exhausted) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_head, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n_items) { exhausted = true; base = n_items; }
-                chunk_next = base;
-                chunk_end = (n_items - base) < chunk ? n_items : base + chunk;
-                avail = chunk_end - chunk_next;
-                const uint32_t rest = cnt - taken;
-                const uint32_t taken2 = rest < avail ? rest : avail;
-                if (want && rank >= taken && (rank - taken) < taken2) my = chunk_next + (rank - taken);
-                chunk_next += taken2;
+            // start on the prefetched ray; lanes without one (first trip, or the queue looked empty) dequeue now
+            const bool cold = want && nx_idx == MISS;
+            const uint32_t now = wave_dequeue(cold, lane, lt_mask, work_head, n_items, chunk, chunk_next, chunk_end, exhausted);
+            if (want) {
+                if (!cold) {
+                    ridx = nx_idx; rtag = nx_tag; wpos = nx_pos; wdir = nx_dir; wtmax = nx_tmax; any = nx_any;
+                } else if (now != MISS) {
+                    ridx = now;
+                    io.load(ridx, wpos, wdir, wtmax, any, rtag);
+                }
+            }
+            const bool started = want && (!cold || now != MISS);
+            // prefetch the ray after this one; its loads complete while the current ray is traced
+            nx_idx = want ? MISS : nx_idx;
+            const uint32_t ahead = wave_dequeue(started, lane, lt_mask, work_head, n_items, chunk, chunk_next, chunk_end, exhausted);
+            if (started && ahead != MISS) {
+                nx_idx = ahead;
+                io.load(nx_idx, nx_pos, nx_dir, nx_tmax, nx_any, nx_tag);
             }
             if (want) {
-                if (my != MISS) {
-                    ridx = my;
-                    io.load(ridx, wpos, wdir, wtmax, any);
+                if (started) {
                     best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
                     root_i = 0; in_tree = false; o_cur = 0; o_end = 0;
                     mesh_pending = false; occluded = false; ofound = false;
@@ -228,7 +306,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const LdsMesh
                 }
             }
         }
+        DIAG_END(phase)
     }
+    DIAG_FLUSH
 }
 
 }  // namespace rtamd

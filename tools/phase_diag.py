@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-phase breakdown of the persistent scheduler kernels (diagnostic build, `make -C rust-raytracer_amd/csrc diag`).
+
+Prints, for FETCH / OBJ / TNODE / NODE / TRI: share of wave cycles, steps executed, mean active lanes per step.
+Run on the GPU box:  RTAMD_LIB=rust-raytracer_amd/librtamd_diag.so python tools/phase_diag.py [--aa 2] [--depth 5]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RTAMD_LIB", os.path.join(ROOT, "rust-raytracer_amd", "librtamd_diag.so"))
+import __graft_entry__ as entry  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--aa", type=int, default=2)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--cam", default="1080x960")
+    ap.add_argument("--opt", default="")
+    args = ap.parse_args()
+    rt = entry.load_package()
+    w, h = map(int, args.cam.split("x"))
+    scene = rt.Scene.main(sky=rt.load_skybox(max_width=2048), cam=(w, h)).upload(0)
+    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE}
+    for kv in filter(None, args.opt.split(",")):
+        k, v = kv.split("=")
+        scene.set_option(opt_ids[k], int(v))
+    lib = rt.rtamd_lib()
+    lib.rtamd_diag_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    buf = (C.c_uint64 * 32)()
+    for depth in sorted({1, args.depth}):
+        scene.render(max_depth=depth, antialiasing=1)  # warm up
+        lib.rtamd_diag_read(scene.ctx, buf, 1)
+        _, st = scene.render(max_depth=depth, shadow_rays=1, antialiasing=args.aa)
+        lib.rtamd_diag_read(scene.ctx, buf, 1)
+        d = np.array(list(buf), dtype=np.float64)[:15].reshape(5, 3)
+        rays = st["closest_rays"] + st["any_rays"]
+        total = d[:, 0].sum()
+        print(f"max_depth {depth}: rays {rays} ({st['closest_rays']} closest, {st['any_rays']} any), device {st['device_ms']:.2f} ms")
+        for name, (cyc, steps, lanes) in zip(("FETCH", "OBJ", "TNODE", "NODE", "TRI"), d):
+            if steps:
+                print(f"  {name:6s} cycles {100 * cyc / total:5.1f}%  steps {int(steps):>12d}  lanes/step {lanes / steps:5.1f}  "
+                      f"cycles/step {cyc / steps:7.1f}  lane-steps/ray {lanes / rays:6.2f}")
+
+
+if __name__ == "__main__":
+    main()
