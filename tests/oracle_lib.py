@@ -192,3 +192,75 @@ def quantize(rgb):
     out = np.zeros(rgb.shape, np.uint8)
     lib().orc_quantize(_fp(rgb), rgb.size, out.ctypes.data_as(_u8p))
     return out
+
+
+# ---- small known-answer probes -----------------------------------------------------------------------
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def kat_moller_trumbore(tri, pos, d):
+    out = (C.c_float * 3)()
+    lib().orc_kat_moller_trumbore((C.c_float * 9)(*[float(x) for x in np.ravel(tri)]), _f3(pos), _f3(d), out)
+    return tuple(out)
+
+
+def kat_triangle_hit(tri, pos, d, t_max=1e12):
+    out = (C.c_float * 3)()
+    lib().orc_kat_triangle_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    hit = lib().orc_kat_triangle_hit((C.c_float * 9)(*[float(x) for x in np.ravel(tri)]), _f3(pos), _f3(d), t_max, out)
+    return bool(hit), tuple(out)
+
+
+def kat_aabb(mn, mx, pos, d):
+    out = (C.c_float * 2)()
+    hit = lib().orc_kat_aabb(_f3(mn), _f3(mx), _f3(pos), _f3(d), out)
+    return bool(hit), tuple(out)
+
+
+def kat_sphere(center, radius, pos, d, t_max=1e12):
+    out = (C.c_float * 5)()
+    lib().orc_kat_sphere.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    hit = lib().orc_kat_sphere(_f3(center), radius, _f3(pos), _f3(d), t_max, out)
+    return bool(hit), dict(t=out[0], pos=(out[1], out[2], out[3]), any=bool(out[4]))
+
+
+def kat_cuboid(a, b, pos, d, t_max=1e12):
+    out = (C.c_float * 8)()
+    lib().orc_kat_cuboid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    hit = lib().orc_kat_cuboid(_f3(a), _f3(b), _f3(pos), _f3(d), t_max, out)
+    return bool(hit), dict(t=out[0], pos=tuple(out[1:4]), norm=tuple(out[4:7]), any=bool(out[7]))
+
+
+def kat_mesh_hit(verts, faces, pos, d, t_max=1e12):
+    verts = np.ascontiguousarray(verts, np.float32)
+    faces = np.ascontiguousarray(faces, np.uint32)
+    prim, face = C.c_uint32(), C.c_uint32()
+    tuv = (C.c_float * 3)()
+    lib().orc_kat_mesh_hit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    hit = lib().orc_kat_mesh_hit(verts.ctypes.data, len(verts), faces.ctypes.data, len(faces), _f3(pos), _f3(d), t_max,
+                                 C.byref(prim), C.byref(face), tuv)
+    return bool(hit), dict(prim=prim.value, face=face.value, t=tuv[0], u=tuv[1], v=tuv[2])
+
+
+def kat_rng(seed, n):
+    u = np.zeros(n, np.uint32)
+    f = np.zeros(n, np.float32)
+    lib().orc_kat_rng.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    lib().orc_kat_rng(seed, n, u.ctypes.data, f.ctypes.data)
+    return u, f
+
+
+def kat_ply(path, n_first=4):
+    counts = np.zeros(2, np.uint32)
+    faces = np.zeros((n_first, 3), np.uint32)
+    lib().orc_kat_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
+    rc = lib().orc_kat_ply(path.encode(), counts.ctypes.data, faces.ctypes.data, n_first)
+    return rc, counts, faces
+
+
+def kat_rotation(axis, angle):
+    out = np.zeros(9, np.float32)
+    lib().orc_kat_rotation.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+    lib().orc_kat_rotation(_f3(axis), angle, out.ctypes.data)
+    return out.reshape(3, 3)

@@ -1,0 +1,185 @@
+"""Analytic known-answer tests that pin the CPU oracle to the reference source.
+
+The reference ships no tests or golden vectors, so each expectation below is derived by hand from the cited lines of
+the reference (src/ paths are relative to the reference repository).  These run on the CPU (no GPU needed).
+"""
+import os
+
+import numpy as np
+import pytest
+
+INF = float("inf")
+TRI = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]
+
+
+def test_triangle_known_hit(ol):
+    # src/geom/triangle.rs:18-38: ray straight down onto the unit right triangle
+    t, u, v = ol.kat_moller_trumbore(TRI, (0.25, 0.25, 1), (0, 0, -1))
+    assert (t, u, v) == (1.0, 0.25, 0.25)
+    hit, tuv = ol.kat_triangle_hit(TRI, (0.25, 0.25, 1), (0, 0, -1))
+    assert hit and tuv == (1.0, 0.25, 0.25)
+
+
+def test_parallel_ray_is_a_hit_at_zero(ol):
+    # triangle.rs:26-28 returns [0,0,0] for |det| < 1e-12, and the accept test of triangle.rs:44 / mesh.rs:130
+    # (t>=0, t<=t_max, u>=0, v>=0, u+v<=1) lets it through: a spurious hit at t = 0
+    assert ol.kat_moller_trumbore(TRI, (-1, 0.2, 0), (1, 0, 0)) == (0.0, 0.0, 0.0)
+    hit, tuv = ol.kat_triangle_hit(TRI, (-1, 0.2, 0), (1, 0, 0))
+    assert hit and tuv == (0.0, 0.0, 0.0)
+
+
+def test_unit_sphere(ol):
+    # src/geom/sphere.rs:22-45: roots (4, 6) from outside; from the centre t0 < 0 so t1 = 1 is taken
+    hit, r = ol.kat_sphere((0, 0, 0), 1.0, (0, 0, -5), (0, 0, 1))
+    assert hit and r["t"] == 4.0 and r["pos"] == (0.0, 0.0, -1.0) and r["any"]
+    hit, r = ol.kat_sphere((0, 0, 0), 1.0, (0, 0, 0), (0, 0, 1))
+    assert hit and r["t"] == 1.0 and r["any"]
+    # behind the ray: t1 < 0
+    hit, r = ol.kat_sphere((0, 0, 0), 1.0, (0, 0, 5), (0, 0, 1))
+    assert not hit and not r["any"]
+
+
+def test_scaled_sphere_doubles_t(ol):
+    # src/geom/transform.rs:102-113: ray pos * inv_scale, t_max * inv_scale going in, t * scale coming out
+    hit, r = ol.kat_sphere((0, 0, 0), 2.0, (0, 0, -10), (0, 0, 1))
+    assert hit and r["t"] == 8.0 and r["pos"] == (0.0, 0.0, -2.0)
+    # t_max halves going in: the unit-space hit at t=4 needs t_max >= 8 in the caller's space
+    assert not ol.kat_sphere((0, 0, 0), 2.0, (0, 0, -10), (0, 0, 1), t_max=7.9)[0]
+    assert ol.kat_sphere((0, 0, 0), 2.0, (0, 0, -10), (0, 0, 1), t_max=8.0)[0]
+
+
+def test_aabb_slab_and_nan_rules(ol):
+    # src/math/aabb.rs:61-87 with the compare-select max!/min! of src/common.rs:31-53
+    box = ((-1, -1, -1), (1, 1, 1))
+    hit, (t0, t1) = ol.kat_aabb(*box, (0, 0, -5), (0, 0, 1))
+    assert hit and (t0, t1) == (4.0, 6.0)            # inv = (inf, inf, 1): a = (-inf,-inf,4), b = (inf,inf,6)
+    hit, (t0, t1) = ol.kat_aabb(*box, (-1, 0, -5), (0, 0, 1))
+    assert hit and (t0, t1) == (4.0, 6.0)            # 0*inf = NaN in slot 0 is dropped by max!(a0, ..)
+    hit, (t0, t1) = ol.kat_aabb(*box, (-5, 0, -1), (1, 0, 0))
+    assert not hit and np.isnan(t0)                  # NaN in slot 2 poisons max!(.., max!(a1, a2))
+    hit, _ = ol.kat_aabb((-1, -1, 0), (1, 1, 0), (0, 0, -5), (0, 0, 1))
+    assert not hit                                   # zero-thickness box through its flat axis: t0 == t1, strict <
+
+
+def test_later_coplanar_triangle_wins_ties(ol):
+    # mesh.rs:130 accepts t <= t_max and bvh.rs:262-264 shrinks t_max to the hit: the later triangle in tree order
+    # replaces an earlier one at the same t
+    verts = [(0, 0, 0), (1, 0, 0.5), (0, 1, 0.5)]   # plane z = (x + y) / 2: hit at z = 0.25, t = 0.75 (all exact in f32)
+    hit, r = ol.kat_mesh_hit(verts, [(0, 1, 2), (0, 1, 2)], (0.25, 0.25, 1), (0, 0, -1))
+    assert hit and r["prim"] == 1 and (r["t"], r["u"], r["v"]) == (0.75, 0.25, 0.25)
+    # consequence of the strict t0 < t1 box test (aabb.rs:82): a mesh whose root box has zero thickness is
+    # invisible to every ray, because both slab distances of the flat axis are equal
+    flat = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]
+    assert not ol.kat_mesh_hit(flat, [(0, 1, 2)], (0.25, 0.25, 1), (0, 0, -1))[0]
+    assert not ol.kat_mesh_hit(flat, [(0, 1, 2)], (0.25, 0.25, 1), (0.0625, 0, -1))[0]
+
+
+def test_camera_centre_pixel_and_quantiser(ol, sky):
+    # src/scene.rs:84-90: u = v = 0 at (w/2, h/2), so the ray direction is the camera direction
+    s = ol.OracleScene.main(sky=sky, cam=(1080, 960))
+    cam, (w, h) = s.camera()
+    rays = s.primary_rays(540, 480, 1, 1)
+    d = cam[3:6].astype(np.float64)
+    assert np.allclose(rays[3:6, 0], d / np.linalg.norm(d), atol=1e-7)
+    assert np.array_equal(rays[0:3, 0], cam[0:3])
+    # src/render.rs:62-72: floor(c*256) clamped to [0,255], no gamma
+    q = ol.quantize(np.array([0.999, 1.0, -0.1, 0.5, 2.0, 0.0], np.float32))
+    assert q.tolist() == [255, 255, 0, 128, 255, 0]
+
+
+def test_ply_loader(ol, tmp_path):
+    # src/loader/ply.rs: bundled file -> 453 vertices / 948 faces; polygons are fan-triangulated (ply.rs:246-248)
+    rc, counts, _ = ol.kat_ply(ol.BUNNY_PLY)
+    assert rc == 0 and counts.tolist() == [453, 948]
+    p = tmp_path / "quad.ply"
+    p.write_text("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                 "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    rc, counts, faces = ol.kat_ply(str(p), 2)
+    assert rc == 0 and counts.tolist() == [4, 2] and faces.tolist() == [[0, 1, 2], [0, 2, 3]]
+    bad = tmp_path / "bad.ply"
+    bad.write_text("ply\nformat binary_little_endian 1.0\nend_header\n")
+    assert ol.kat_ply(str(bad))[0] != 0
+
+
+def test_skip_link_invariants(ol, sky):
+    # src/geom/bvh.rs:148,164-165: sentinel = (empty, m, n); inner nodes have an empty range; leaf sizes sum to n;
+    # skip links point forward; a leaf's skip is the next node
+    s = ol.OracleScene.main(sky=sky, cam=(64, 64))
+    nodes, order, stats = s.bvh(0)
+    m = len(nodes) - 1
+    skip, first = nodes[:, 6], nodes[:, 7]
+    assert skip[m] == m and first[m] == 948
+    assert np.array_equal(nodes[m, :3].view(np.float32), [INF] * 3) and np.array_equal(nodes[m, 3:6].view(np.float32), [-INF] * 3)
+    sizes = first[1:].astype(np.int64) - first[:-1].astype(np.int64)
+    assert (sizes >= 0).all() and sizes.sum() == 948
+    leaf = sizes > 0
+    assert np.array_equal(skip[:-1][leaf], np.arange(m)[leaf] + 1)
+    assert (skip[:-1] > np.arange(m)).all() and (skip[:-1] <= m).all()
+    assert sorted(order.tolist()) == list(range(948))
+    assert stats.tolist() == [948, len(nodes), int(leaf.sum()), int(sizes[leaf].min()), int(sizes[leaf].max())]
+    # every triangle lies inside its leaf box and the root box
+    verts, _ = s.mesh_data()
+    ply_faces = np.array([l.split()[1:4] for l in open(ol.BUNNY_PLY).read().split("end_header\n")[1].splitlines()[453:453 + 948]], np.int64)
+    boxes = nodes[:, :6].view(np.float32)
+    for i in np.nonzero(leaf)[0][:20]:
+        tri = verts[ply_faces[order[first[i]:first[i + 1]]]].reshape(-1, 3)
+        assert (tri >= boxes[i, :3]).all() and (tri <= boxes[i, 3:]).all()
+
+
+def test_rotation_matrix_keeps_reference_formula(ol):
+    # src/math/mat3d.rs:59 writes `y*z*(1.0*c) - x*s`; for the x axis (the only axis main.rs uses) this is harmless
+    m = ol.kat_rotation((1, 0, 0), np.float32(np.pi / 2))
+    assert abs(m[0, 0] - 1.0) < 1e-7 and m[0, 1] == 0.0 and m[0, 2] == 0.0  # c + (1 - c) rounds just below 1 in f32
+    assert abs(m[1, 2] + 1.0) < 1e-7 and abs(m[2, 1] - 1.0) < 1e-7 and abs(m[1, 1]) < 1e-7
+    g = ol.kat_rotation((0, 1, 1), np.float32(0.7))  # general axis: the (1,2) entry follows the reference, not Rodrigues
+    c, s_ = np.cos(np.float32(0.7)), np.sin(np.float32(0.7))
+    y = z = np.float32(1 / np.sqrt(2))
+    assert abs(g[1, 2] - (y * z * c - 0 * s_)) < 1e-6
+
+
+def test_rng_stream_properties(ol):
+    # rand 0.6 SmallRng (PCG Mcg128Xsl64 seeded through seed_from_u64).  No reference vector exists (parity
+    # unpinned); these checks pin what the published algorithm guarantees.
+    u, f = ol.kat_rng(0x0123456789ABCDEF, 4096)
+    u2, _ = ol.kat_rng(0x0123456789ABCDEF, 4096)
+    assert np.array_equal(u, u2)
+    assert np.array_equal(f, (u >> 8).astype(np.float32) * np.float32(2.0 ** -24))  # Standard f32: 24 bits * 2^-24
+    assert 0.0 <= f.min() and f.max() < 1.0 and abs(f.mean() - 0.5) < 0.02
+    v, _ = ol.kat_rng(0x0123456789ABCDEE, 64)
+    assert not np.array_equal(u[:64], v)
+    # independent Python restatement of the same published recurrence
+    def ref(seed, n):
+        M64 = (1 << 64) - 1
+        st, words = seed, []
+        for _ in range(4):
+            st = (st * 6364136223846793005 + 11634580027462260723) & M64
+            xs = (((st >> 18) ^ st) >> 27) & 0xFFFFFFFF
+            rot = st >> 59
+            words.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        state = (words[0] | words[1] << 32 | words[2] << 64 | words[3] << 96) | 1
+        out = []
+        for _ in range(n):
+            state = (state * 0x2360ED051FC65DA44385DF649FCCF645) & ((1 << 128) - 1)
+            rot = state >> 122
+            xsl = ((state >> 64) ^ state) & M64
+            out.append(((xsl >> rot) | (xsl << ((64 - rot) & 63))) & 0xFFFFFFFF)
+        return out
+    assert u[:32].tolist() == ref(0x0123456789ABCDEF, 32)
+
+
+def test_cuboid_matches_hand_computation(ol):
+    # src/geom/cuboid.rs:19-48,82-93: floor slab from above; normal is the dominant axis of the unit-cube point
+    hit, r = ol.kat_cuboid((-5, -5, 0), (5, 5, -1), (1, 2, 3), (0, 0, -1))
+    assert hit and r["t"] == 3.0 and r["pos"] == (1.0, 2.0, 0.0) and r["norm"] == (0.0, 0.0, 1.0) and r["any"]
+    hit, r = ol.kat_cuboid((-5, -5, 0), (5, 5, -1), (1, 2, 3), (0, 0, 1))
+    assert not hit and not r["any"]
+
+
+def test_render_is_deterministic_and_tile_invariant(ol, sky):
+    # integrator.rs:36: the seed depends only on (cx, cy), so a sub-rectangle reproduces the full frame's pixels
+    s = ol.OracleScene.main(sky=sky, cam=(96, 80))
+    full, _, _ = s.render(max_depth=4, antialiasing=2, threads=4)
+    again, _, _ = s.render(max_depth=4, antialiasing=2, threads=2)
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32))
+    part, _, _ = s.render(max_depth=4, antialiasing=2, rect=(30, 20, 40, 30), threads=3)
+    assert np.array_equal(part.view(np.uint32), full[20:50, 30:70].view(np.uint32))
