@@ -5,6 +5,7 @@
 namespace rtamd {
 
 static constexpr int TRACE_BLOCK = 512;  // threads per block of the traversal kernels (8 waves)
+static constexpr int STAGE_BLOCK = 1024; // threads per block of the queue-building stages (one queue atomic per block)
 #ifndef RTAMD_SCHED_WAVES
 #define RTAMD_SCHED_WAVES 5
 #endif

@@ -326,17 +326,35 @@ __device__ __forceinline__ void light_sample(const DevLight& l, f3 normal, Rng& 
     }
 }
 
-// wave64 compaction: lanes with `take` get consecutive slots of a global queue; one atomic per wave.
-__device__ __forceinline__ uint32_t wave_append(bool take, uint32_t* counter) {
+// Block-wide compaction: threads with `take` get consecutive slots of a global queue.  The waves
+// of a block pool their counts in LDS and the block issues ONE atomic.  A single queue counter sustains only ~90 atomics/us, so stages that
+// append from every wave are bound by it unless they aggregate.  Every thread of the block must
+// call this (it synchronises); `sh` holds one word per wave.
+template <int NWAVES>
+__device__ __forceinline__ uint32_t block_append(bool take, uint32_t* counter, uint32_t* sh) {
+    static_assert(NWAVES <= 64, "one scan lane per wave");
     unsigned long long mask = __ballot(take);
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t before = __popcll(mask & ((1ULL << lane) - 1ULL));
-    uint32_t total = __popcll(mask);
-    uint32_t base = 0;
-    int leader = mask ? (__ffsll((long long)mask) - 1) : 0;
-    if (take && (int)lane == leader) base = atomicAdd(counter, total);
-    base = __shfl(base, leader);
-    return base + before;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t before = __popcll(mask & ((1ULL << lane) - 1ULL));
+    if (lane == 0) sh[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t v = lane < (uint32_t)NWAVES ? sh[lane] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < NWAVES; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        const uint32_t sum = __shfl(incl, NWAVES - 1);
+        uint32_t base = 0;
+        if (lane == 0 && sum) base = atomicAdd(counter, sum);
+        base = __shfl(base, 0);
+        if (lane < (uint32_t)NWAVES) sh[lane] = base + incl - v;
+    }
+    __syncthreads();
+    // sh[wave] is next overwritten by this same wave, so no third barrier is needed
+    return sh[wave] + before;
 }
 
 // Pixel slot -> pixel coordinates of the owned tile set (see rtamd_region).
@@ -356,8 +374,9 @@ __device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, ui
 // antialiasing grid (src/integrator.rs:33-48).  Also folds the previous sample's radiance into the
 // pixel sum (integrator.rs:50-53 adds the samples in generation order).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_raygen(WaveBufs W, RegionDev R, CameraDev cam, uint32_t chunk_begin, uint32_t chunk_n,
+__global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R, CameraDev cam, uint32_t chunk_begin, uint32_t chunk_n,
                                                 uint32_t si, uint32_t sj, uint32_t aa, uint32_t first_sample, uint32_t q_idx) {
+    __shared__ uint32_t sh_app[STAGE_BLOCK / 64];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     uint32_t cx = 0, cy = 0;
@@ -385,7 +404,7 @@ __global__ __launch_bounds__(256) void k_raygen(WaveBufs W, RegionDev R, CameraD
         dir = normalize(d);
         pos = cam.pos;
     }
-    uint32_t q = wave_append(valid, &W.counts[q_idx]);
+    uint32_t q = block_append<STAGE_BLOCK / 64>(valid, &W.counts[q_idx], sh_app);
     if (valid) {
         W.q_slot[0][q] = i;
         float* r = W.q_ray[0];
@@ -469,8 +488,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
 // then draw the scatter direction and append the continuation ray to the next path queue.  The
 // per-pixel random stream is consumed in exactly the order of the reference's recursion.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint32_t cur, int32_t depth, int32_t max_depth, int32_t shadow_rays,
+__global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs W, uint32_t cur, int32_t depth, int32_t max_depth, int32_t shadow_rays,
                                                     uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx) {
+    __shared__ uint32_t sh_app[STAGE_BLOCK / 64];
     const uint32_t n = W.counts[q_in_idx];
     const float* r = cur ? W.q_ray[1] : W.q_ray[0];
     const uint32_t* q_slot_in = cur ? W.q_slot[1] : W.q_slot[0];
@@ -515,7 +535,7 @@ __global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint
                 lit = !is_zero(diffuse);                               // integrator.rs:80
             }
         }
-        uint32_t lq = wave_append(lit, &W.counts[lit_idx]);
+        uint32_t lq = block_append<STAGE_BLOCK / 64>(lit, &W.counts[lit_idx], sh_app);
         // ---- phase B: draw light samples, then the scatter direction (same stream order) ----
         f3 next_pos = mk(0, 0, 0), next_dir = mk(0, 0, 0);
         Rng rng; rng.lo = 0; rng.hi = 0;
@@ -541,7 +561,7 @@ __global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint
                         q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z;
                         shoot = !(tm == 0.0f);                         // integrator.rs:124
                     }
-                    uint32_t aq = wave_append(shoot, &W.counts[any_idx]);
+                    uint32_t aq = block_append<STAGE_BLOCK / 64>(shoot, &W.counts[any_idx], sh_app);
                     if (shoot) {
                         float* a = W.a_ray;
                         a[aq] = p.x; a[aq + ac] = p.y; a[aq + 2 * ac] = p.z;
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(256) void k_wave_shade(DevScene S, WaveBufs W, uint
             W.rng_lo[slot] = rng.lo; W.rng_hi[slot] = rng.hi;
         }
         // ---- compaction of the continuing paths into the next ray queue ----
-        uint32_t nq = wave_append(cont, &W.counts[q_out_idx]);
+        uint32_t nq = block_append<STAGE_BLOCK / 64>(cont, &W.counts[q_out_idx], sh_app);
         if (cont) {
             q_slot_out[nq] = slot;
             float* o = q_ray_out;
@@ -724,8 +744,8 @@ hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBa
 }
 hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
                          uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t q_idx, hipStream_t st) {
-    uint32_t g = (chunk_n + 255) / 256;
-    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(256), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, first ? 1u : 0u, q_idx);
+    uint32_t g = (chunk_n + STAGE_BLOCK - 1) / STAGE_BLOCK;
+    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(STAGE_BLOCK), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, first ? 1u : 0u, q_idx);
     return hipGetLastError();
 }
 hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st) {
@@ -743,11 +763,11 @@ hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const Wave
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
                              int shadow_rays, uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st) {
-    size_t need = (upper + 255) / 256;
-    size_t capg = (size_t)cfg.num_cus * 8;
+    size_t need = (upper + STAGE_BLOCK - 1) / STAGE_BLOCK;
+    size_t capg = (size_t)cfg.num_cus * (2048 / STAGE_BLOCK);
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
-    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(256), 0, st, S, W, cur, depth, max_depth, shadow_rays, q_in, q_out, lit_idx, any_idx);
+    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, cur, depth, max_depth, shadow_rays, q_in, q_out, lit_idx, any_idx);
     return hipGetLastError();
 }
 hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, size_t upper, hipStream_t st) {
