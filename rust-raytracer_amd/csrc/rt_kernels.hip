@@ -123,10 +123,15 @@ struct BatchIO {
     HitBatch hits;
     uint8_t* any_out;
     bool any_mode;
-    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
-        pos = mk(rays.ox[i], rays.oy[i], rays.oz[i]);
-        dir = mk(rays.dx[i], rays.dy[i], rays.dz[i]);
-        tmax = rays.tmax[i];
+    __device__ __forceinline__ void stage(uint32_t i, uint32_t (&raw)[8]) const {
+        raw[0] = __float_as_uint(rays.ox[i]); raw[1] = __float_as_uint(rays.oy[i]); raw[2] = __float_as_uint(rays.oz[i]);
+        raw[3] = __float_as_uint(rays.dx[i]); raw[4] = __float_as_uint(rays.dy[i]); raw[5] = __float_as_uint(rays.dz[i]);
+        raw[6] = __float_as_uint(rays.tmax[i]);
+    }
+    __device__ __forceinline__ void decode(uint32_t, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
+        pos = mk(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]));
+        dir = mk(__uint_as_float(raw[3]), __uint_as_float(raw[4]), __uint_as_float(raw[5]));
+        tmax = __uint_as_float(raw[6]);
         any = any_mode;
         tag = 0;
     }
@@ -148,11 +153,12 @@ struct BatchIO {
 template <int MESHLOC, bool TAB_LDS>
 __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
     if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;  // enough earlier blocks exist to cover the batch
+    const uint32_t head_claim = claim_chunk(work_head, chunk);  // in flight while the scene is staged
     LdsMesh lds;
     LdsTab ltab;
     stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk);
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, head_claim);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, head_claim);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,24 +434,26 @@ struct WaveIO {
     uint8_t* vis;
     uint32_t cap, any_cap;
     uint32_t n_closest;
-    __device__ __forceinline__ void load(uint32_t i, f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
-        if (i < n_closest) {
-            const float* r = q_ray;
-            pos = mk(r[i], r[i + cap], r[i + 2 * cap]);
-            dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
-            tmax = 1e12f;
-            any = false;
-            tag = 0;
-        } else {
-            const uint32_t j = i - n_closest;
-            const size_t ac = any_cap;
-            const float* r = a_ray;
-            pos = mk(r[j], r[j + ac], r[j + 2 * ac]);
-            dir = mk(r[j + 3 * ac], r[j + 4 * ac], r[j + 5 * ac]);
-            tmax = r[j + 6 * ac];
-            any = true;
-            tag = a_vidx[j];
-        }
+    // Closest-hit rays are items [0, n_closest), shadow rays follow.  Addresses are selected per lane,
+    // the loads themselves are unconditional (words 6 and 7 of a closest-hit ray are ignored).
+    __device__ __forceinline__ void stage(uint32_t i, uint32_t (&raw)[8]) const {
+        const bool a = i >= n_closest;
+        const uint32_t j = a ? i - n_closest : i;
+        const float* base = (a ? a_ray : q_ray) + j;
+        const size_t stride = a ? any_cap : cap;
+        const float* p6 = a ? base + 6 * stride : base;
+        const uint32_t* p7 = a ? a_vidx + j : (const uint32_t*)base;
+#pragma unroll
+        for (int c = 0; c < 6; c++) raw[c] = __float_as_uint(base[c * stride]);
+        raw[6] = __float_as_uint(*p6);
+        raw[7] = *p7;
+    }
+    __device__ __forceinline__ void decode(uint32_t i, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
+        pos = mk(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]));
+        dir = mk(__uint_as_float(raw[3]), __uint_as_float(raw[4]), __uint_as_float(raw[5]));
+        any = i >= n_closest;
+        tmax = any ? __uint_as_float(raw[6]) : 1e12f;
+        tag = raw[7];
     }
     __device__ __forceinline__ void store_closest(uint32_t i, uint32_t, bool found, const Best& b, float) const {
         h_obj[i] = found ? b.obj : MISS;
@@ -469,16 +477,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
         W.stats[1] += n_any;
     }
     if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;
-    LdsMesh lds;
-    LdsTab ltab;
-    stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
-    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_obj, W.h_prim, W.h_f, W.vis, W.cap, W.any_cap, n_closest};
     // small queues: smaller chunks so that more waves share the work
     uint32_t chunk = chunk_hint;
     const uint32_t waves = gridDim.x * (TRACE_BLOCK / 64);
     while (chunk > 64 && (n / chunk) < waves) chunk >>= 1;
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk);
+    const uint32_t head_claim = claim_chunk(&W.counts[head_idx], chunk);  // in flight while the scene is staged
+    LdsMesh lds;
+    LdsTab ltab;
+    stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
+    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_obj, W.h_prim, W.h_f, W.vis, W.cap, W.any_cap, n_closest};
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, head_claim);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, head_claim);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,15 +8,18 @@
 // over the SAME per-ray operation sequence as the reference (so results stay bit-identical), and
 // each trip of the wave's loop executes the one phase that the most lanes are waiting for:
 //
-//   FETCH  store the finished ray's result, start on the prefetched next ray, prefetch another
+//   FETCH  store the finished ray's result, start on a ray of the wave's staged batch
 //   OBJ    fold a finished mesh walk, step the root list / object-tree leaf, enter the next object
 //          (ray-space wrappers, 1/dir) or intersect a non-mesh primitive
 //   TNODE  one node of an object tree (world space)
 //   NODE   one node of a mesh tree (object space)
 //   TRI    one triangle of the current leaf
 //
-// Lanes that run out of work refill from a global queue head in chunks (one atomic per wave per
-// chunk), so a wave stays full until the queue is empty.
+// Lanes that run out of work are refilled from a batch of 64 consecutive rays that the wave keeps
+// staged in registers (lane l holds ray batch_base + l; a lane that needs a ray pulls it across
+// lanes with ds_bpermute).  The batch after it is requested the moment the staged one is used up,
+// and the queue head is advanced one chunk ahead of need, so neither the ray loads nor the atomic
+// are waited for in the step that issues them: their latency overlaps the traversal phases.
 #pragma once
 #include "rt_device.h"
 
@@ -54,43 +57,26 @@ __device__ unsigned long long g_diag[32];
 #define DIAG_FLUSH
 #endif
 
-// Wave-aggregated dequeue: lanes with `want` receive consecutive ray indices (MISS when the queue
-// is empty).  chunk_next / chunk_end / exhausted are wave-uniform; must be called in uniform flow.
-__device__ __forceinline__ uint32_t wave_dequeue(bool want, uint32_t lane, unsigned long long lt_mask, uint32_t* work_head, uint32_t n_items,
-                                                 uint32_t chunk, uint32_t& chunk_next, uint32_t& chunk_end, bool& exhausted) {
-    const unsigned long long need = __ballot(want);
-    if (need == 0ull) return MISS;
-    const uint32_t cnt = __popcll(need), rank = __popcll(need & lt_mask);
-    uint32_t avail = chunk_end - chunk_next;
-    const uint32_t taken = cnt < avail ? cnt : avail;
-    uint32_t my = MISS;
-    if (want && rank < taken) my = chunk_next + rank;
-    chunk_next += taken;
-    if (taken < cnt && !exhausted) {  // one refill is enough: chunk >= 64
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(work_head, chunk);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n_items) { exhausted = true; base = n_items; }
-        chunk_next = base;
-        chunk_end = (n_items - base) < chunk ? n_items : base + chunk;
-        avail = chunk_end - chunk_next;
-        const uint32_t rest = cnt - taken;
-        const uint32_t taken2 = rest < avail ? rest : avail;
-        if (want && rank >= taken && (rank - taken) < taken2) my = chunk_next + (rank - taken);
-        chunk_next += taken2;
-    }
-    return my;
+// Claims the next chunk of the work queue; the returned value is valid in lane 0 only and should be
+// read (wave_first) as late as possible so that the atomic's latency is hidden.
+__device__ __forceinline__ uint32_t claim_chunk(uint32_t* work_head, uint32_t chunk) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(work_head, chunk);
+    return base;
 }
 
 // IO concept:
-//   void load(uint32_t idx, f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const;
+//   void stage(uint32_t idx, uint32_t (&raw)[8]) const;   // issue the loads of ray idx; no branches around loads
+//   void decode(uint32_t idx, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const;
 //   void store_closest(uint32_t idx, uint32_t tag, bool found, const Best& b, float t_world) const;
 //   void store_any(uint32_t idx, uint32_t tag, bool occluded) const;
 // `tag` is an opaque word the IO wants back when the result is stored (loaded with the ray, so that
-// storing never needs a dependent read).
+// storing never needs a dependent read).  stage() must load straight into raw[] in uniform control
+// flow: a load behind a divergent branch lands in a temporary that is merged right away, which puts
+// the wait for it next to the load.
 template <int MESHLOC, class Tab, class IO>
 __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
-                                                const uint32_t n_items, const uint32_t chunk) {
+                                                const uint32_t n_items, const uint32_t chunk, uint32_t head_claim) {
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
@@ -100,11 +86,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     f3 wpos = mk(0, 0, 0), wdir = mk(0, 0, 1), winv = mk(0, 0, 0);
     bool wngx = false, wngy = false, wngz = false;
     float wtmax = 0.0f;
-    // prefetched next ray of this lane (its loads are issued one ray ahead of use)
-    uint32_t nx_idx = MISS, nx_tag = 0;
-    f3 nx_pos = mk(0, 0, 0), nx_dir = mk(0, 0, 1);
-    float nx_tmax = 0.0f;
-    bool nx_any = false;
+    // staged batch: lane l holds the raw words of ray sg_base + l, l < sg_cnt; sg_pos rays are handed out
+    uint32_t sg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t sg_base = 0, sg_cnt = 0, sg_pos = 0;  // wave-uniform
     Best best;
     best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
     uint32_t root_i = 0;
@@ -276,35 +260,49 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 if (any) io.store_any(ridx, rtag, occluded);
                 else io.store_closest(ridx, rtag, best.obj != MISS, best, wtmax);
             }
-            // start on the prefetched ray; lanes without one (first trip, or the queue looked empty) dequeue now
-            const bool cold = want && nx_idx == MISS;
-            const uint32_t now = wave_dequeue(cold, lane, lt_mask, work_head, n_items, chunk, chunk_next, chunk_end, exhausted);
-            if (want) {
-                if (!cold) {
-                    ridx = nx_idx; rtag = nx_tag; wpos = nx_pos; wdir = nx_dir; wtmax = nx_tmax; any = nx_any;
-                } else if (now != MISS) {
-                    ridx = now;
-                    io.load(ridx, wpos, wdir, wtmax, any, rtag);
-                }
-            }
-            const bool started = want && (!cold || now != MISS);
-            // prefetch the ray after this one; its loads complete while the current ray is traced
-            nx_idx = want ? MISS : nx_idx;
-            const uint32_t ahead = wave_dequeue(started, lane, lt_mask, work_head, n_items, chunk, chunk_next, chunk_end, exhausted);
-            if (started && ahead != MISS) {
-                nx_idx = ahead;
-                io.load(nx_idx, nx_pos, nx_dir, nx_tmax, nx_any, nx_tag);
-            }
-            if (want) {
-                if (started) {
+            // hand out staged rays to the lanes that want one
+            const unsigned long long need = __ballot(want);
+            const uint32_t rank = __popcll(need & lt_mask);
+            const uint32_t avail = sg_cnt - sg_pos;
+            const uint32_t take = c_fetch < avail ? c_fetch : avail;
+            if (take > 0) {
+                const uint32_t src = sg_pos + rank;
+                uint32_t raw[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) raw[c] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)sg[c]);
+                if (want && rank < take) {
+                    ridx = sg_base + src;
+                    io.decode(ridx, raw, wpos, wdir, wtmax, any, rtag);
                     best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
                     root_i = 0; in_tree = false; o_cur = 0; o_end = 0;
                     mesh_pending = false; occluded = false; ofound = false;
                     st = ST_OBJ;
-                } else {
-                    st = ST_DONE;
+                }
+                sg_pos += take;
+            }
+            // staged batch used up: request the next one now, it is consumed in a later FETCH step
+            if (sg_pos == sg_cnt && !exhausted) {
+                if (chunk_next == chunk_end) {
+                    const uint32_t base = __builtin_amdgcn_readfirstlane(head_claim);
+                    if (base >= n_items) {
+                        exhausted = true;
+                    } else {
+                        chunk_next = base;
+                        chunk_end = (n_items - base) < chunk ? n_items : base + chunk;
+                        head_claim = claim_chunk(work_head, chunk);
+                    }
+                }
+                sg_pos = 0;
+                sg_cnt = 0;
+                if (!exhausted) {
+                    const uint32_t left = chunk_end - chunk_next;
+                    sg_base = chunk_next;
+                    sg_cnt = left < 64u ? left : 64u;
+                    chunk_next += sg_cnt;
+                    io.stage(sg_base + (lane < sg_cnt ? lane : sg_cnt - 1u), sg);
                 }
             }
+            if (st == ST_FETCH && exhausted && sg_cnt == 0) st = ST_DONE;
         }
         DIAG_END(phase)
     }
