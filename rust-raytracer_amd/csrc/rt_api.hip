@@ -28,11 +28,18 @@ struct rtamd_context {
     uint32_t total_samples_lights = 0;   // not used on the host; kept for introspection
     std::vector<rtamd_light> lights;
 
-    // wavefront workspace
-    WaveBufs W{};
-    std::vector<void*> wave_allocs;
-    size_t wave_cap = 0;
-    uint32_t wave_samples = 0;
+    // wavefront workspaces: one per pixel group in flight, each with its own stream, so that the
+    // short late-bounce launches of one group overlap the long launches of another
+    struct Workspace {
+        WaveBufs W{};
+        std::vector<void*> allocs;
+        size_t cap = 0;
+        uint32_t samples = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    std::vector<Workspace> ws;
+    int n_streams = 4;
 
     // ray batch workspace of the host-pointer entry points
     void* batch_buf = nullptr;
@@ -117,45 +124,50 @@ uint32_t light_samples(const rtamd_light& l, int shadow_rays) {
 }
 
 template <class T>
-int wave_alloc(rtamd_context* ctx, T** p, size_t count) {
+int wave_alloc(rtamd_context* ctx, rtamd_context::Workspace& ws, T** p, size_t count) {
     void* q = nullptr;
     HIP_TRY(ctx, hipMalloc(&q, count * sizeof(T) + 256));
-    ctx->wave_allocs.push_back(q);
+    ws.allocs.push_back(q);
     *p = (T*)q;
     return RTAMD_OK;
 }
 
-int ensure_wave(rtamd_context* ctx, size_t cap, uint32_t samples) {
-    if (ctx->wave_cap >= cap && ctx->wave_samples >= samples) return RTAMD_OK;
-    free_list(ctx->wave_allocs);
-    ctx->wave_cap = 0; ctx->wave_samples = 0;
-    WaveBufs& W = ctx->W;
+int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, uint32_t samples) {
+    if (!ws.stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+    }
+    if (ws.cap >= cap && ws.samples >= samples) return RTAMD_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ws.stream));
+    free_list(ws.allocs);
+    ws.cap = 0; ws.samples = 0;
+    WaveBufs& W = ws.W;
     int rc;
     const size_t S = samples ? samples : 1;
     if (cap * S > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "chunk size x light samples exceeds 2^32; lower RTAMD_OPT_MAX_PATHS");
     W.cap = (uint32_t)cap;
     W.any_cap = (uint32_t)(cap * S);
-    if ((rc = wave_alloc(ctx, &W.rng_lo, cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.rng_hi, cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.sum, 3 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.L, 3 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.beta, 3 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.rng_lo, cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.rng_hi, cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.sum, 3 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.L, 3 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.beta, 3 * cap))) return rc;
     for (int k = 0; k < 2; k++) {
-        if ((rc = wave_alloc(ctx, &W.q_slot[k], cap))) return rc;
-        if ((rc = wave_alloc(ctx, &W.q_ray[k], 6 * cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &W.q_slot[k], cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &W.q_ray[k], 6 * cap))) return rc;
     }
-    if ((rc = wave_alloc(ctx, &W.h_obj, cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.h_prim, cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.h_f, 3 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.lit_slot, cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.lit_f, 6 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.smp, 4 * S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.a_ray, 7 * S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.a_vidx, S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.vis, S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, &W.counts, (size_t)CounterSlots::TOTAL))) return rc;
-    if ((rc = wave_alloc(ctx, &W.stats, (size_t)16))) return rc;
-    ctx->wave_cap = cap; ctx->wave_samples = samples;
+    if ((rc = wave_alloc(ctx, ws, &W.h_obj, cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.h_prim, cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.h_f, 3 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.lit_slot, cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.lit_f, 6 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.smp, 4 * S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.a_ray, 7 * S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.a_vidx, S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.vis, S * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.counts, (size_t)CounterSlots::TOTAL))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.stats, (size_t)16))) return rc;
+    ws.cap = cap; ws.samples = samples;
     return RTAMD_OK;
 }
 
@@ -257,7 +269,12 @@ void rtamd_destroy(rtamd_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_list(ctx->scene_allocs);
-    free_list(ctx->wave_allocs);
+    for (auto& w : ctx->ws) {
+        if (w.stream) (void)hipStreamSynchronize(w.stream);
+        free_list(w.allocs);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
     if (ctx->batch_buf) (void)hipFree(ctx->batch_buf);
     if (ctx->work_head) (void)hipFree(ctx->work_head);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -284,6 +301,10 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
         case RTAMD_OPT_BLOCKS_PER_CU:
             if (value < 1 || value > 8) return fail(ctx, RTAMD_E_INVALID, "blocks per CU must be in [1, 8]");
             ctx->cfg.sched_blocks_per_cu = (int)value;
+            return RTAMD_OK;
+        case RTAMD_OPT_STREAMS:
+            if (value < 1 || value > 8) return fail(ctx, RTAMD_E_INVALID, "streams must be in [1, 8]");
+            ctx->n_streams = (int)value;
             return RTAMD_OK;
         default: return fail(ctx, RTAMD_E_INVALID, "unknown option");
     }
@@ -369,6 +390,20 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         if (ob.geom_kind == RTAMD_GEOM_MESH) {
             d.node_base = meshes[ob.geom_index].node_base; d.n_nodes = meshes[ob.geom_index].n_nodes; d.tri_base = meshes[ob.geom_index].tri_base;
         }
+        // inline wrapper parameters when the chain is a subsequence of Translate, Scale, Rotate
+        d.scale = 1.0f; d.inv_scale = 1.0f;
+        uint32_t last = 0;
+        for (uint32_t k = 0; k < ob.op_count && d.xf_kind != XF_GENERIC; k++) {
+            const rtamd_xform_op& op = sc->ops[ob.op_first + k];
+            const uint32_t bit = op.kind == RTAMD_OP_TRANSLATE ? XF_T : op.kind == RTAMD_OP_SCALE ? XF_S : op.kind == RTAMD_OP_ROTATE ? XF_R : XF_GENERIC;
+            if (bit == XF_GENERIC || bit <= last) { d.xf_kind = XF_GENERIC; break; }
+            last = bit;
+            d.xf_kind |= bit;
+            if (bit == XF_T) std::memcpy(d.off, op.v, 12);
+            else if (bit == XF_S) { d.scale = op.v[0]; d.inv_scale = op.v[1]; }
+            else std::memcpy(d.rot, op.v, 36);
+        }
+        if (d.xf_kind == XF_GENERIC) { d.scale = 1.0f; d.inv_scale = 1.0f; }
         objects.push_back(d);
     }
     std::vector<DevOp> ops;
@@ -456,7 +491,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
     {
-        size_t tb = (size_t)sc->n_objects * 32 + (size_t)sc->n_ops * 48 + (size_t)sc->n_cuboids * 48 + (((size_t)sc->n_root * 8 + 15) & ~(size_t)15);
+        size_t tb = (size_t)sc->n_objects * sizeof(DevObject) + (size_t)sc->n_ops * 48 + (size_t)sc->n_cuboids * 48 + (((size_t)sc->n_root * 8 + 15) & ~(size_t)15);
         S.tab_bytes = tb <= 8192 ? (uint32_t)tb : 0u;
     }
     ctx->S = S;
@@ -562,12 +597,19 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     const size_t total_slots = rtamd_region_pixels(region);
     if (total_slots == 0) return RTAMD_OK;
     if (total_slots > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "region too large");
-    const size_t cap = std::min(total_slots, ctx->max_paths);
-    int rc = ensure_wave(ctx, cap, S_total);
-    if (rc) return rc;
-    WaveBufs W = ctx->W;
-    W.cap = (uint32_t)ctx->wave_cap;
-    hipStream_t st = ctx->stream;
+    // pixel groups: at most n_streams in flight, none smaller than 64 Ki pixels unless the region is
+    const size_t G = (size_t)ctx->n_streams;
+    size_t cap = (total_slots + G - 1) / G;
+    cap = std::max<size_t>(cap, 65536);
+    cap = (cap + 1023) / 1024 * 1024;
+    cap = std::min(std::min(cap, total_slots), ctx->max_paths);
+    const size_t n_groups = (total_slots + cap - 1) / cap;
+    const size_t n_ws = std::min(G, n_groups);
+    if (ctx->ws.size() < n_ws) ctx->ws.resize(n_ws);
+    for (size_t w = 0; w < n_ws; w++) {
+        int rc = ensure_wave(ctx, ctx->ws[w], cap, S_total);
+        if (rc) return rc;
+    }
     RegionDev R = make_region(*region);
     CameraDev C;
     C.pos = f3{cam->pos[0], cam->pos[1], cam->pos[2]};
@@ -577,19 +619,36 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     C.width = cam->width; C.height = cam->height;
 
     hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(W.stats, 0, 32, st));
-    HIP_TRY(ctx, hipEventRecord(ev0, st));
+    HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    for (size_t w = 0; w < n_ws; w++) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->ws[w].stream, ev0, 0));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ws[w].W.stats, 0, 32, ctx->ws[w].stream));
+    }
     uint64_t launches = 0;
     const uint32_t aa = (uint32_t)integ->antialiasing;
     const int D = integ->max_depth;
     typedef CounterSlots CS;
-    for (size_t begin = 0; begin < total_slots; begin += cap) {
-        const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
-        const size_t any_upper = (size_t)chunk_n * (S_total ? S_total : 1);
-        for (uint32_t si = 0; si < aa; si++) {
-            for (uint32_t sj = 0; sj < aa; sj++) {
+    // The sample passes of the groups are enqueued round-robin so that the host feeds every stream
+    // from the start instead of finishing one group's command list first.
+    for (size_t g0 = 0; g0 < n_groups; g0 += n_ws) {
+        const size_t g1 = std::min(n_groups, g0 + n_ws);
+        for (uint32_t pass = 0; pass <= aa * aa; pass++) {
+            for (size_t g = g0; g < g1; g++) {
+                rtamd_context::Workspace& ws = ctx->ws[g - g0];
+                WaveBufs W = ws.W;
+                W.cap = (uint32_t)ws.cap;
+                hipStream_t st = ws.stream;
+                const size_t begin = g * cap;
+                const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
+                const size_t any_upper = (size_t)chunk_n * (S_total ? S_total : 1);
+                if (pass == aa * aa) {
+                    HIP_TRY(ctx, launch_finalize(W, R, (uint32_t)begin, chunk_n, (float)(aa * aa), out, st));
+                    launches++;
+                    continue;
+                }
+                const uint32_t si = pass / aa, sj = pass % aa;
                 HIP_TRY(ctx, hipMemsetAsync(W.counts, 0, CS::TOTAL * 4, st));
-                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, si == 0 && sj == 0, CS::Q + 0, st));
+                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, pass == 0, CS::Q + 0, st));
                 launches++;
                 uint32_t cur = 0;
                 if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
@@ -623,13 +682,16 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                 }
             }
         }
-        HIP_TRY(ctx, launch_finalize(W, R, (uint32_t)begin, chunk_n, (float)(aa * aa), out, st));
-        launches++;
     }
-    HIP_TRY(ctx, hipEventRecord(ev1, st));
-    uint64_t hstats[4] = {0, 0, 0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(hstats, W.stats, 32, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::vector<uint64_t> hstats(4 * n_ws, 0);
+    for (size_t w = 0; w < n_ws; w++) {
+        HIP_TRY(ctx, hipMemcpyAsync(&hstats[4 * w], ctx->ws[w].W.stats, 32, hipMemcpyDeviceToHost, ctx->ws[w].stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ws[w].done, ctx->ws[w].stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws[w].done, 0));
+    }
+    HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t w = 1; w < n_ws; w++) { hstats[0] += hstats[4 * w]; hstats[1] += hstats[4 * w + 1]; }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     ctx->event_pool.push_back(ev0);

@@ -32,8 +32,18 @@ struct DevTree { uint32_t node_base, n_nodes, first_object, pad; };
 struct DevCuboid { float center[3], extent[3], inv_extent[3]; float pad[3]; };
 struct DevTriangle { float a[3], b[3], c[3]; float pad[3]; };
 struct DevOp { uint32_t kind; float v[9]; uint32_t pad[2]; };
-// mesh objects carry a copy of their mesh record, so entering an object is one 32-byte read
-struct DevObject { uint32_t geom_kind, geom_index, material, op_first, op_count, node_base, n_nodes, tri_base; };
+// 96 bytes = 6 x float4.  Mesh objects carry a copy of their mesh record.  When the wrapper chain of
+// the object is a subsequence of Translate -> Scale -> Rotate (outermost first, each at most once:
+// what the reference's scenes build), xf_kind has the XF_T / XF_S / XF_R bits and the parameters sit
+// in the record itself, so entering the object needs no walk over the op list; any other chain sets
+// XF_GENERIC and is walked op by op.  scale = 1 when the chain has no Scale.
+struct DevObject {
+    uint32_t geom_kind, geom_index, material, xf_kind;
+    uint32_t op_first, op_count, node_base, n_nodes;
+    uint32_t tri_base; float scale, inv_scale; uint32_t pad;
+    float off[3]; float rot[9];
+};
+enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8 };
 struct DevRootItem { uint32_t kind, index; };
 struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t pad[2]; };
 struct DevLight { uint32_t kind; float vec[3]; float param; float emission[3]; };
@@ -259,11 +269,24 @@ __device__ __forceinline__ float4 lds_load4(lds_float4* p) {
 struct OpRec { uint32_t kind; float v[9]; };
 struct CuboidRec { f3 center, extent, inv_extent; };
 
-__device__ __forceinline__ DevObject unpack_object(float4 a, float4 b) {
-    DevObject o;
-    o.geom_kind = __float_as_uint(a.x); o.geom_index = __float_as_uint(a.y); o.material = __float_as_uint(a.z); o.op_first = __float_as_uint(a.w);
-    o.op_count = __float_as_uint(b.x); o.node_base = __float_as_uint(b.y); o.n_nodes = __float_as_uint(b.z); o.tri_base = __float_as_uint(b.w);
+// Head of an object record (the first three float4) and its inline wrapper parameters (the last three).
+struct ObjHead {
+    uint32_t geom_kind, geom_index, material, xf_kind, op_first, op_count, node_base, n_nodes, tri_base;
+    float scale, inv_scale;
+};
+struct ObjXf { f3 off; float rot[9]; };
+__device__ __forceinline__ ObjHead unpack_object(float4 a, float4 b, float4 c) {
+    ObjHead o;
+    o.geom_kind = __float_as_uint(a.x); o.geom_index = __float_as_uint(a.y); o.material = __float_as_uint(a.z); o.xf_kind = __float_as_uint(a.w);
+    o.op_first = __float_as_uint(b.x); o.op_count = __float_as_uint(b.y); o.node_base = __float_as_uint(b.z); o.n_nodes = __float_as_uint(b.w);
+    o.tri_base = __float_as_uint(c.x); o.scale = c.y; o.inv_scale = c.z;
     return o;
+}
+__device__ __forceinline__ ObjXf unpack_xf(float4 d, float4 e, float4 f) {
+    ObjXf x;
+    x.off = mk(d.x, d.y, d.z);
+    x.rot[0] = d.w; x.rot[1] = e.x; x.rot[2] = e.y; x.rot[3] = e.z; x.rot[4] = e.w; x.rot[5] = f.x; x.rot[6] = f.y; x.rot[7] = f.z; x.rot[8] = f.w;
+    return x;
 }
 __device__ __forceinline__ OpRec unpack_op(float4 a, float4 b, float4 c) {
     OpRec o;
@@ -278,17 +301,19 @@ __device__ __forceinline__ CuboidRec unpack_cuboid(float4 a, float4 b, float4 c)
 }
 struct GlobalTab {
     const DevScene* S;
-    __device__ __forceinline__ DevObject object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1]); }
+    __device__ __forceinline__ ObjHead object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1], p[2]); }
+    __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_xf(p[3], p[4], p[5]); }
     __device__ __forceinline__ OpRec op(uint32_t i) const { const float4* p = (const float4*)(S->ops + i); return unpack_op(p[0], p[1], p[2]); }
     __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { const float4* p = (const float4*)(S->cuboids + i); return unpack_cuboid(p[0], p[1], p[2]); }
     __device__ __forceinline__ DevRootItem root(uint32_t i) const { return S->root[i]; }
 };
 struct LdsTab {
-    lds_float4* objects;  // 2 per object
+    lds_float4* objects;  // 6 per object
     lds_float4* ops;      // 3 per op
     lds_float4* cuboids;  // 3 per cuboid
     __attribute__((address_space(3))) const uint32_t* roots;  // kind, index pairs
-    __device__ __forceinline__ DevObject object(uint32_t i) const { return unpack_object(lds_load4(objects + 2 * i), lds_load4(objects + 2 * i + 1)); }
+    __device__ __forceinline__ ObjHead object(uint32_t i) const { return unpack_object(lds_load4(objects + 6 * i), lds_load4(objects + 6 * i + 1), lds_load4(objects + 6 * i + 2)); }
+    __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { return unpack_xf(lds_load4(objects + 6 * i + 3), lds_load4(objects + 6 * i + 4), lds_load4(objects + 6 * i + 5)); }
     __device__ __forceinline__ OpRec op(uint32_t i) const { return unpack_op(lds_load4(ops + 3 * i), lds_load4(ops + 3 * i + 1), lds_load4(ops + 3 * i + 2)); }
     __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { return unpack_cuboid(lds_load4(cuboids + 3 * i), lds_load4(cuboids + 3 * i + 1), lds_load4(cuboids + 3 * i + 2)); }
     __device__ __forceinline__ DevRootItem root(uint32_t i) const { return DevRootItem{roots[2 * i], roots[2 * i + 1]}; }
@@ -337,6 +362,14 @@ __device__ __forceinline__ void ops_hit_out(const Tab& tab, uint32_t first, uint
     }
 }
 
+// The same wrappers applied from an object record's inline parameters (xf_kind without XF_GENERIC):
+// identical operations in identical order, without the walk over the op list.
+__device__ __forceinline__ void xf_in(uint32_t xf_kind, const ObjXf& x, float inv_scale, f3& pos, f3& dir, float& t_max) {
+    if (xf_kind & XF_T) pos = pos - x.off;
+    if (xf_kind & XF_S) { pos = pos * inv_scale; t_max = t_max * inv_scale; }
+    if (xf_kind & XF_R) { pos = mat_transpose_apply(x.rot, pos); dir = mat_transpose_apply(x.rot, dir); }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Closest-hit state of one ray.
 // ------------------------------------------------------------------------------------------------
@@ -349,7 +382,7 @@ struct Best {
 // Cuboid::hit -> UnitCuboid::hit (cuboid.rs:82-93,19-28), Triangle::hit (triangle.rs:41-44).
 // u, v are only produced for the triangle; sphere / cuboid uv come from reconstruct_hit().
 template <class Tab>
-__device__ __forceinline__ bool primitive_closest(const DevScene& S, const Tab& tab, const DevObject& ob, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
+__device__ __forceinline__ bool primitive_closest(const DevScene& S, const Tab& tab, const ObjHead& ob, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
     if (ob.geom_kind == GEOM_UNIT_SPHERE) {
         return unit_sphere_hit(pos, dir, t_max, t);
     } else if (ob.geom_kind == GEOM_CUBOID) {
@@ -371,7 +404,7 @@ __device__ __forceinline__ bool primitive_closest(const DevScene& S, const Tab& 
 // (cuboid.rs:95-100, world-space slab with Ray::inv_dir), UnitCuboid::is_hit (cuboid.rs:50-54),
 // Triangle::is_hit (triangle.rs:59-62).
 template <class Tab>
-__device__ __forceinline__ bool primitive_any(const DevScene& S, const Tab& tab, const DevObject& ob, f3 pos, f3 dir, float t_max) {
+__device__ __forceinline__ bool primitive_any(const DevScene& S, const Tab& tab, const ObjHead& ob, f3 pos, f3 dir, float t_max) {
     if (ob.geom_kind == GEOM_UNIT_SPHERE) {
         return unit_sphere_any(pos, dir, t_max);
     } else if (ob.geom_kind == GEOM_CUBOID) {
@@ -401,7 +434,7 @@ __device__ __forceinline__ bool primitive_any(const DevScene& S, const Tab& tab,
 template <class Mem>
 __device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds_mem, uint32_t oi, f3 pos, f3 dir, float& t_max, Best& best) {
     const GlobalTab tab{&S};
-    const DevObject ob = tab.object(oi);
+    const ObjHead ob = tab.object(oi);
     float tl_max = t_max;
     ops_in(tab, ob.op_first, ob.op_count, pos, dir, tl_max);
     float t = 0.0f, u = 0.0f, v = 0.0f;
@@ -430,7 +463,7 @@ __device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds
 template <class Mem>
 __device__ __forceinline__ bool object_any(const DevScene& S, const Mem* lds_mem, uint32_t oi, f3 pos, f3 dir, float t_max) {
     const GlobalTab tab{&S};
-    const DevObject ob = tab.object(oi);
+    const ObjHead ob = tab.object(oi);
     ops_in(tab, ob.op_first, ob.op_count, pos, dir, t_max);
     if (ob.geom_kind == GEOM_MESH) {
         const DevMesh m = S.meshes[ob.geom_index];
@@ -517,7 +550,7 @@ __device__ __forceinline__ bool scene_any(const DevScene& S, const Mem* lds_mem,
 // operations as the traversal did.
 __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b, f3 pos, f3 dir, f3& hpos, f3& hnorm, float& hu, float& hv) {
     const GlobalTab tab{&S};
-    const DevObject ob = tab.object(b.obj);
+    const ObjHead ob = tab.object(b.obj);
     float dummy = 0.0f;
     ops_in(tab, ob.op_first, ob.op_count, pos, dir, dummy);
     f3 p, n;

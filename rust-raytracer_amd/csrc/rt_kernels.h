@@ -7,9 +7,9 @@ namespace rtamd {
 static constexpr int TRACE_BLOCK = 512;  // threads per block of the traversal kernels (8 waves)
 static constexpr int STAGE_BLOCK = 1024; // threads per block of the queue-building stages (one queue atomic per block)
 #ifndef RTAMD_SCHED_WAVES
-#define RTAMD_SCHED_WAVES 5
+#define RTAMD_SCHED_WAVES 4
 #endif
-static constexpr int SCHED_WAVES_PER_SIMD = RTAMD_SCHED_WAVES;  // register budget of the scheduler kernels (6 waves/SIMD spills and is slower)
+static constexpr int SCHED_WAVES_PER_SIMD = RTAMD_SCHED_WAVES;  // register budget of the scheduler kernels: two 8-wave blocks per CU = 4 waves/SIMD, 128 VGPRs
 
 struct RayBatch { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };
 struct HitBatch { uint32_t *obj, *prim; float *t, *u, *v; };

@@ -100,7 +100,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         base = n_mesh4;
     }
     if (TAB_LDS) {
-        const uint32_t n_obj4 = 2 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
+        const uint32_t n_obj4 = 6 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
         const float4* go = (const float4*)S.objects;
         const float4* gp = (const float4*)S.ops;
         const float4* gc = (const float4*)S.cuboids;
@@ -123,10 +123,10 @@ struct BatchIO {
     HitBatch hits;
     uint8_t* any_out;
     bool any_mode;
-    __device__ __forceinline__ void stage(uint32_t i, uint32_t (&raw)[8]) const {
-        raw[0] = __float_as_uint(rays.ox[i]); raw[1] = __float_as_uint(rays.oy[i]); raw[2] = __float_as_uint(rays.oz[i]);
-        raw[3] = __float_as_uint(rays.dx[i]); raw[4] = __float_as_uint(rays.dy[i]); raw[5] = __float_as_uint(rays.dz[i]);
-        raw[6] = __float_as_uint(rays.tmax[i]);
+    __device__ __forceinline__ void stage_addr(uint32_t i, const void* (&src)[8]) const {
+        src[0] = rays.ox + i; src[1] = rays.oy + i; src[2] = rays.oz + i;
+        src[3] = rays.dx + i; src[4] = rays.dy + i; src[5] = rays.dz + i;
+        src[6] = rays.tmax + i; src[7] = rays.tmax + i;
     }
     __device__ __forceinline__ void decode(uint32_t, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
         pos = mk(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]));
@@ -153,12 +153,13 @@ struct BatchIO {
 template <int MESHLOC, bool TAB_LDS>
 __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
     if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;  // enough earlier blocks exist to cover the batch
-    const uint32_t head_claim = claim_chunk(work_head, chunk);  // in flight while the scene is staged
+    __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
     LdsMesh lds;
     LdsTab ltab;
     stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, head_claim);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, head_claim);
+    lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, stage);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -434,19 +435,17 @@ struct WaveIO {
     uint8_t* vis;
     uint32_t cap, any_cap;
     uint32_t n_closest;
-    // Closest-hit rays are items [0, n_closest), shadow rays follow.  Addresses are selected per lane,
-    // the loads themselves are unconditional (words 6 and 7 of a closest-hit ray are ignored).
-    __device__ __forceinline__ void stage(uint32_t i, uint32_t (&raw)[8]) const {
+    // Closest-hit rays are items [0, n_closest), shadow rays follow (words 6 and 7 of a closest-hit ray
+    // are ignored and point at its first word).
+    __device__ __forceinline__ void stage_addr(uint32_t i, const void* (&src)[8]) const {
         const bool a = i >= n_closest;
         const uint32_t j = a ? i - n_closest : i;
         const float* base = (a ? a_ray : q_ray) + j;
         const size_t stride = a ? any_cap : cap;
-        const float* p6 = a ? base + 6 * stride : base;
-        const uint32_t* p7 = a ? a_vidx + j : (const uint32_t*)base;
 #pragma unroll
-        for (int c = 0; c < 6; c++) raw[c] = __float_as_uint(base[c * stride]);
-        raw[6] = __float_as_uint(*p6);
-        raw[7] = *p7;
+        for (int c = 0; c < 6; c++) src[c] = base + c * stride;
+        src[6] = a ? base + 6 * stride : base;
+        src[7] = a ? (const void*)(a_vidx + j) : (const void*)base;
     }
     __device__ __forceinline__ void decode(uint32_t i, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
         pos = mk(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]));
@@ -481,13 +480,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
     uint32_t chunk = chunk_hint;
     const uint32_t waves = gridDim.x * (TRACE_BLOCK / 64);
     while (chunk > 64 && (n / chunk) < waves) chunk >>= 1;
-    const uint32_t head_claim = claim_chunk(&W.counts[head_idx], chunk);  // in flight while the scene is staged
+    __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
+    lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
     LdsMesh lds;
     LdsTab ltab;
     stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
     WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_obj, W.h_prim, W.h_f, W.vis, W.cap, W.any_cap, n_closest};
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, head_claim);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, head_claim);
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage);
 }
 
 // ------------------------------------------------------------------------------------------------

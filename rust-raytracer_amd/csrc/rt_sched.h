@@ -16,10 +16,11 @@
 //   TRI    one triangle of the current leaf
 //
 // Lanes that run out of work are refilled from a batch of 64 consecutive rays that the wave keeps
-// staged in registers (lane l holds ray batch_base + l; a lane that needs a ray pulls it across
-// lanes with ds_bpermute).  The batch after it is requested the moment the staged one is used up,
-// and the queue head is advanced one chunk ahead of need, so neither the ray loads nor the atomic
-// are waited for in the step that issues them: their latency overlaps the traversal phases.
+// staged in its own 2 KB of LDS.  The batch is fetched with direct global->LDS loads
+// (global_load_lds_dword, issued from inline asm so that the compiler's s_waitcnt bookkeeping does
+// not see them) the moment the previous batch is used up, and is only waited for (one explicit
+// s_waitcnt vmcnt(0)) in the later FETCH step that first reads it: the ray loads' latency overlaps
+// the traversal phases, and no register holds a pending load.
 #pragma once
 #include "rt_device.h"
 
@@ -57,50 +58,72 @@ __device__ unsigned long long g_diag[32];
 #define DIAG_FLUSH
 #endif
 
-// Claims the next chunk of the work queue; the returned value is valid in lane 0 only and should be
-// read (wave_first) as late as possible so that the atomic's latency is hidden.
+// Claims the next chunk of the work queue for the wave (one atomic per chunk).
 __device__ __forceinline__ uint32_t claim_chunk(uint32_t* work_head, uint32_t chunk) {
     uint32_t base = 0;
     if (lane_id() == 0) base = atomicAdd(work_head, chunk);
-    return base;
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// Per-wave ray staging buffer in LDS: 8 rows (one per raw word of a ray) of 64 dwords.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+static constexpr uint32_t STAGE_WORDS = 8 * 64;
+// One row of the staging buffer: lane l's dword at gsrc lands at lds_dst + 4 * l.  lds_dst is the
+// wave-uniform LDS byte address of the row.  M0 carries the LDS base of a direct-to-LDS load and is
+// saved and restored inside the statement.
+__device__ __forceinline__ void stage_row(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
 }
 
 // IO concept:
-//   void stage(uint32_t idx, uint32_t (&raw)[8]) const;   // issue the loads of ray idx; no branches around loads
+//   void stage_addr(uint32_t idx, const void* (&src)[8]) const;   // where the 8 raw words of ray idx live
 //   void decode(uint32_t idx, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const;
 //   void store_closest(uint32_t idx, uint32_t tag, bool found, const Best& b, float t_world) const;
 //   void store_any(uint32_t idx, uint32_t tag, bool occluded) const;
 // `tag` is an opaque word the IO wants back when the result is stored (loaded with the ray, so that
-// storing never needs a dependent read).  stage() must load straight into raw[] in uniform control
-// flow: a load behind a divergent branch lands in a temporary that is merged right away, which puts
-// the wait for it next to the load.
+// storing never needs a dependent read).  Every address stage_addr() returns must be readable, also
+// for words the ray kind does not use.
+// Per-lane boolean state lives in one VGPR word (`fl`).  Kept as separate bools the compiler holds
+// each one as a 64-bit lane mask in SGPRs and spends three scalar instructions per bool at every
+// control-flow join of the loop; as bits of a vector register an update is one v_or / v_and.
+enum : uint32_t {
+    F_ANY = 1u,       // the ray is an occlusion query
+    F_HAVE = 2u,      // a finished ray's result waits to be stored
+    F_OCC = 4u,       // occlusion query: something was hit
+    F_INTREE = 8u,    // walking an object tree
+    F_MLDS = 16u,     // the current mesh is the LDS-resident one (MESH_MIXED only)
+    F_PEND = 32u,     // a mesh walk ended and has not been folded into the ray's state yet
+    F_FOUND = 64u,    // the current mesh walk accepted a triangle
+    F_GENXF = 128u    // the current object's wrapper chain must be walked op by op
+};
+__device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t)__builtin_popcountll(__ballot(p)); }
+
 template <int MESHLOC, class Tab, class IO>
 __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
-                                                const uint32_t n_items, const uint32_t chunk, uint32_t head_claim) {
+                                                const uint32_t n_items, const uint32_t chunk, lds_u32* stage /* this wave's STAGE_WORDS */) {
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
-    uint32_t st = ST_FETCH;
-    bool have = false, any = false, occluded = false;
+    uint32_t st = ST_FETCH, fl = 0;
     uint32_t ridx = 0, rtag = 0;
     f3 wpos = mk(0, 0, 0), wdir = mk(0, 0, 1), winv = mk(0, 0, 0);
-    bool wngx = false, wngy = false, wngz = false;
     float wtmax = 0.0f;
-    // staged batch: lane l holds the raw words of ray sg_base + l, l < sg_cnt; sg_pos rays are handed out
-    uint32_t sg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // staged batch: row c of `stage` holds raw word c of rays sg_base .. sg_base + sg_cnt - 1; sg_pos are handed out
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
     uint32_t sg_base = 0, sg_cnt = 0, sg_pos = 0;  // wave-uniform
     Best best;
     best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
     uint32_t root_i = 0;
-    bool in_tree = false;
     uint32_t t_i = 0, t_n = 0, t_base = 0, t_first = 0;
     uint32_t o_cur = 0, o_end = 0;
     uint32_t oi = 0, op_first = 0, op_count = 0;
     f3 opos = mk(0, 0, 0), odir = mk(0, 0, 1), oinv = mk(0, 0, 0);
-    bool ongx = false, ongy = false, ongz = false;
-    float otmax = 0.0f;
+    float otmax = 0.0f, oscale = 1.0f;
     uint32_t n_i = 0, n_n = 0, node_off = 0, tri_off = 0;
-    bool mesh_lds = false, mesh_pending = false, ofound = false;
     uint32_t k_cur = 0, k_end = 0, oprim = 0;
     float ou = 0.f, ov = 0.f;
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
@@ -110,26 +133,28 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     for (;;) {
         DIAG_TOP
         // ---- vote: run the phase most lanes are waiting for ----
-        const uint32_t c_tri = __popcll(__ballot(st == ST_TRI));
-        const uint32_t c_node = __popcll(__ballot(st == ST_NODE));
-        const uint32_t c_tnode = __popcll(__ballot(st == ST_TNODE));
-        const uint32_t c_obj = __popcll(__ballot(st == ST_OBJ));
-        const uint32_t c_fetch = __popcll(__ballot(st == ST_FETCH));
-        if (c_tri + c_node + c_tnode + c_obj + c_fetch == 0) break;  // every lane is ST_DONE
-        uint32_t phase = ST_TRI, top = c_tri;
-        if (c_node > top) { top = c_node; phase = ST_NODE; }
-        if (c_tnode > top) { top = c_tnode; phase = ST_TNODE; }
-        if (c_obj > top) { top = c_obj; phase = ST_OBJ; }
-        if (c_fetch > top) { top = c_fetch; phase = ST_FETCH; }
+        const uint32_t c_tri = wave_count(st == ST_TRI);
+        const uint32_t c_node = wave_count(st == ST_NODE);
+        const uint32_t c_tnode = wave_count(st == ST_TNODE);
+        const uint32_t c_obj = wave_count(st == ST_OBJ);
+        const uint32_t c_fetch = wave_count(st == ST_FETCH);
+        if ((c_tri | c_node | c_tnode | c_obj | c_fetch) == 0) break;  // every lane is ST_DONE
+        // most lanes wins; ties go to the deeper phase (the state codes grow with depth)
+        uint32_t key = (c_tri << 3) | ST_TRI;
+        key = max(key, (c_node << 3) | ST_NODE);
+        key = max(key, (c_tnode << 3) | ST_TNODE);
+        key = max(key, (c_obj << 3) | ST_OBJ);
+        key = max(key, (c_fetch << 3) | ST_FETCH);
+        const uint32_t phase = key & 7u;
 
         if (phase == ST_TRI) {
           // stay in the phase while at least STAY_NUM/STAY_DEN of the lanes that entered it still need it:
           // one ballot per step instead of a full vote
-          for (uint32_t c = c_tri; c * STAY_DEN >= c_tri * STAY_NUM && c > 0; c = __popcll(__ballot(st == ST_TRI))) {
+          for (uint32_t c = c_tri; c * STAY_DEN >= c_tri * STAY_NUM && c > 0; c = wave_count(st == ST_TRI)) {
             DIAG_STEP(ST_TRI, c)
             if (st == ST_TRI) {
                 float4 q0, q1, q2;
-                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && mesh_lds)) {
+                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && (fl & F_MLDS))) {
                     lds_float4* tp = lds.tris + 3 * k_cur;
                     q0 = lds_load4(tp); q1 = lds_load4(tp + 1); q2 = lds_load4(tp + 2);
                 } else {
@@ -137,23 +162,25 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
                 }
                 float t, u, v;
-                if (tri_test(q0, q1, q2, opos, odir, otmax, t, u, v)) {
-                    if (any) { occluded = true; have = true; st = ST_FETCH; }
-                    else { otmax = t; oprim = k_cur; ou = u; ov = v; ofound = true; }
-                }
+                const bool hit = tri_test(q0, q1, q2, opos, odir, otmax, t, u, v);
+                const bool is_any = (fl & F_ANY) != 0u;
+                const bool hit_c = hit && !is_any, hit_a = hit && is_any;
+                // closest: a later triangle with t <= t_max replaces the earlier one (mesh.rs:130)
+                otmax = hit_c ? t : otmax; oprim = hit_c ? k_cur : oprim; ou = hit_c ? u : ou; ov = hit_c ? v : ov;
                 k_cur++;
-                if (st == ST_TRI && k_cur >= k_end) {  // leaf done: i += 1 (bvh.rs:245)
-                    n_i++;
-                    if (n_i >= n_n) { mesh_pending = true; st = ST_OBJ; } else st = ST_NODE;
-                }
+                const bool leaf_done = k_cur >= k_end;          // leaf done: i += 1 (bvh.rs:245)
+                n_i += leaf_done ? 1u : 0u;
+                const bool mesh_done = leaf_done && n_i >= n_n;
+                fl |= (hit_c ? F_FOUND : 0u) | (hit_a ? (F_OCC | F_HAVE) : 0u) | ((mesh_done && !hit_a) ? F_PEND : 0u);
+                st = hit_a ? ST_FETCH : (leaf_done ? (mesh_done ? ST_OBJ : ST_NODE) : ST_TRI);
             }
           }
         } else if (phase == ST_NODE) {
-          for (uint32_t c = c_node; c * STAY_DEN >= c_node * STAY_NUM && c > 0; c = __popcll(__ballot(st == ST_NODE))) {
+          for (uint32_t c = c_node; c * STAY_DEN >= c_node * STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
             if (st == ST_NODE) {
                 float4 n0, n1;
-                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && mesh_lds)) {
+                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && (fl & F_MLDS))) {
                     lds_float4* np = lds.nodes + 2 * n_i;
                     n0 = lds_load4(np); n1 = lds_load4(np + 1);
                 } else {
@@ -162,52 +189,52 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 }
                 const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
                 const bool leaf = (A & LEAF_BIT) != 0u;
-                if (node_passes(n0, n1, opos, oinv, ongx, ongy, ongz, otmax)) {
-                    if (leaf && (A & ~LEAF_BIT) < B) { k_cur = A & ~LEAF_BIT; k_end = B; st = ST_TRI; }
-                    else n_i++;
-                } else {
-                    n_i = leaf ? n_i + 1 : A;
-                }
-                if (st == ST_NODE && n_i >= n_n) { mesh_pending = true; st = ST_OBJ; }
+                const uint32_t first = A & ~LEAF_BIT;
+                const bool pass = node_passes(n0, n1, opos, oinv, signbit32(oinv.x), signbit32(oinv.y), signbit32(oinv.z), otmax);
+                const bool enter = pass && leaf && first < B;
+                k_cur = enter ? first : k_cur; k_end = enter ? B : k_end;
+                n_i = enter ? n_i : ((pass || leaf) ? n_i + 1 : A);   // skip link on a failed inner node
+                const bool mesh_done = !enter && n_i >= n_n;
+                fl |= mesh_done ? F_PEND : 0u;
+                st = enter ? ST_TRI : (mesh_done ? ST_OBJ : ST_NODE);
             }
           }
         } else if (phase == ST_TNODE) {
-          for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * STAY_NUM && c > 0; c = __popcll(__ballot(st == ST_TNODE))) {
+          for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * STAY_NUM && c > 0; c = wave_count(st == ST_TNODE)) {
             DIAG_STEP(ST_TNODE, c)
             if (st == ST_TNODE) {
                 const float4* np = S.nodes + 2 * ((size_t)t_base + t_i);
                 float4 n0 = np[0], n1 = np[1];
                 const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
                 const bool leaf = (A & LEAF_BIT) != 0u;
-                if (node_passes(n0, n1, wpos, winv, wngx, wngy, wngz, wtmax)) {
-                    if (leaf && (A & ~LEAF_BIT) < B) { o_cur = t_first + (A & ~LEAF_BIT); o_end = t_first + B; st = ST_OBJ; }
-                    else t_i++;
-                } else {
-                    t_i = leaf ? t_i + 1 : A;
-                }
-                if (st == ST_TNODE && t_i >= t_n) { in_tree = false; st = ST_OBJ; }
+                const uint32_t first = A & ~LEAF_BIT;
+                const bool pass = node_passes(n0, n1, wpos, winv, signbit32(winv.x), signbit32(winv.y), signbit32(winv.z), wtmax);
+                const bool enter = pass && leaf && first < B;
+                o_cur = enter ? t_first + first : o_cur; o_end = enter ? t_first + B : o_end;
+                t_i = enter ? t_i : ((pass || leaf) ? t_i + 1 : A);
+                const bool tree_done = !enter && t_i >= t_n;
+                fl &= tree_done ? ~F_INTREE : ~0u;
+                st = (enter || tree_done) ? ST_OBJ : ST_TNODE;
             }
           }
         } else if (phase == ST_OBJ) {
             DIAG_STEP(ST_OBJ, c_obj)
             if (st == ST_OBJ) {
                 // (1) fold a finished mesh walk into the ray's closest hit (bvh.rs:262-264, transform.rs:107)
-                if (mesh_pending) {
-                    mesh_pending = false;
-                    if (ofound) {
-                        best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
-                        wtmax = ops_t_out(tab, op_first, op_count, otmax);
-                    }
+                if ((fl & (F_PEND | F_FOUND)) == (F_PEND | F_FOUND)) {
+                    best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
+                    wtmax = (fl & F_GENXF) ? ops_t_out(tab, op_first, op_count, otmax) : otmax * oscale;
                 }
+                fl &= ~(F_PEND | F_FOUND);
                 // (2) where does the next object come from?
                 if (o_cur == o_end) {
-                    if (in_tree) {  // leaf of the object tree finished: i += 1
+                    if (fl & F_INTREE) {  // leaf of the object tree finished: i += 1
                         t_i++;
-                        if (t_i >= t_n) in_tree = false; else st = ST_TNODE;
+                        if (t_i >= t_n) fl &= ~F_INTREE; else st = ST_TNODE;
                     }
-                    if (!in_tree && st == ST_OBJ) {
+                    if (!(fl & F_INTREE) && st == ST_OBJ) {
                         if (root_i >= S.n_root) {
-                            have = true; st = ST_FETCH;  // GeometryList exhausted: the ray is finished
+                            fl |= F_HAVE; st = ST_FETCH;  // GeometryList exhausted: the ray is finished
                         } else {
                             const DevRootItem it = tab.root(root_i++);
                             if (it.kind == ROOT_OBJECT) { o_cur = it.index; o_end = it.index + 1; }
@@ -215,8 +242,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                                 const DevTree tr = S.trees[it.index];
                                 t_base = tr.node_base; t_n = tr.n_nodes; t_first = tr.first_object; t_i = 0;
                                 winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // bvh.rs:220
-                                wngx = signbit32(winv.x); wngy = signbit32(winv.y); wngz = signbit32(winv.z);
-                                if (t_n > 0) { in_tree = true; st = ST_TNODE; }
+                                if (t_n > 0) { fl |= F_INTREE; st = ST_TNODE; }
                             }
                         }
                     }
@@ -224,72 +250,79 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 // (3) enter the next object
                 if (st == ST_OBJ && o_cur < o_end) {
                     oi = o_cur++;
-                    const DevObject ob = tab.object(oi);
+                    const ObjHead ob = tab.object(oi);
                     op_first = ob.op_first; op_count = ob.op_count;
                     opos = wpos; odir = wdir; otmax = wtmax;
-                    ops_in(tab, op_first, op_count, opos, odir, otmax);
+                    oscale = ob.scale;
+                    if (ob.xf_kind & XF_GENERIC) {
+                        fl |= F_GENXF;
+                        ops_in(tab, op_first, op_count, opos, odir, otmax);
+                    } else {
+                        fl &= ~F_GENXF;
+                        if (ob.xf_kind) xf_in(ob.xf_kind, tab.object_xf(oi), ob.inv_scale, opos, odir, otmax);
+                    }
                     if (ob.geom_kind == GEOM_MESH) {
                         n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
-                        mesh_lds = (MESHLOC != MESH_GLOBAL) && (ob.geom_index == S.lds_mesh);
+                        if (MESHLOC == MESH_MIXED) fl = (ob.geom_index == S.lds_mesh) ? (fl | F_MLDS) : (fl & ~F_MLDS);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
-                        ongx = signbit32(oinv.x); ongy = signbit32(oinv.y); ongz = signbit32(oinv.z);
-                        ofound = false;
                         if (n_n > 0) st = ST_NODE;
                     } else {
                         float t = 0.0f;
                         bool hit;
-                        if (any) {
+                        if (fl & F_ANY) {
                             hit = primitive_any(S, tab, ob, opos, odir, otmax);
+                            if (hit) { fl |= F_OCC | F_HAVE; st = ST_FETCH; }
                         } else {
                             float u = 0.f, v = 0.f;
                             hit = primitive_closest(S, tab, ob, opos, odir, otmax, t, u, v);
                             if (hit) {
                                 best.obj = oi; best.prim = 0; best.t_local = t; best.u = u; best.v = v;
-                                wtmax = ops_t_out(tab, op_first, op_count, t);
+                                wtmax = (fl & F_GENXF) ? ops_t_out(tab, op_first, op_count, t) : t * oscale;
                             }
                         }
-                        if (any && hit) { occluded = true; have = true; st = ST_FETCH; }
                     }
                 }
             }
         } else {  // ST_FETCH
             DIAG_STEP(ST_FETCH, c_fetch)
             const bool want = st == ST_FETCH;
-            if (want && have) {
-                have = false;
-                if (any) io.store_any(ridx, rtag, occluded);
-                else io.store_closest(ridx, rtag, best.obj != MISS, best, wtmax);
-            }
             // hand out staged rays to the lanes that want one
             const unsigned long long need = __ballot(want);
-            const uint32_t rank = __popcll(need & lt_mask);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(need & lt_mask);
             const uint32_t avail = sg_cnt - sg_pos;
             const uint32_t take = c_fetch < avail ? c_fetch : avail;
+            const bool got = want && rank < take;
+            uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (take > 0) {
-                const uint32_t src = sg_pos + rank;
-                uint32_t raw[8];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the batch was requested in an earlier FETCH step
+                const uint32_t src = (sg_pos + rank) & 63u;
 #pragma unroll
-                for (int c = 0; c < 8; c++) raw[c] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)sg[c]);
-                if (want && rank < take) {
-                    ridx = sg_base + src;
-                    io.decode(ridx, raw, wpos, wdir, wtmax, any, rtag);
-                    best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
-                    root_i = 0; in_tree = false; o_cur = 0; o_end = 0;
-                    mesh_pending = false; occluded = false; ofound = false;
-                    st = ST_OBJ;
-                }
-                sg_pos += take;
+                for (int c = 0; c < 8; c++) raw[c] = stage[c * 64 + src];
             }
-            // staged batch used up: request the next one now, it is consumed in a later FETCH step
+            if (want && (fl & F_HAVE)) {
+                if (fl & F_ANY) io.store_any(ridx, rtag, (fl & F_OCC) != 0u);
+                else io.store_closest(ridx, rtag, best.obj != MISS, best, wtmax);
+            }
+            fl &= want ? ~F_HAVE : ~0u;
+            if (got) {
+                bool any;
+                ridx = sg_base + sg_pos + rank;
+                io.decode(ridx, raw, wpos, wdir, wtmax, any, rtag);
+                best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
+                root_i = 0; o_cur = 0; o_end = 0;
+                fl = any ? F_ANY : 0u;
+                st = ST_OBJ;
+            }
+            sg_pos += take;
+            // staged batch used up: request the next one now, it is read in a later FETCH step
             if (sg_pos == sg_cnt && !exhausted) {
                 if (chunk_next == chunk_end) {
-                    const uint32_t base = __builtin_amdgcn_readfirstlane(head_claim);
+                    const uint32_t base = claim_chunk(work_head, chunk);
                     if (base >= n_items) {
                         exhausted = true;
                     } else {
                         chunk_next = base;
                         chunk_end = (n_items - base) < chunk ? n_items : base + chunk;
-                        head_claim = claim_chunk(work_head, chunk);
                     }
                 }
                 sg_pos = 0;
@@ -299,7 +332,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     sg_base = chunk_next;
                     sg_cnt = left < 64u ? left : 64u;
                     chunk_next += sg_cnt;
-                    io.stage(sg_base + (lane < sg_cnt ? lane : sg_cnt - 1u), sg);
+                    const void* src[8];
+                    io.stage_addr(sg_base + (lane < sg_cnt ? lane : sg_cnt - 1u), src);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of the old batch have returned
+#pragma unroll
+                    for (int c = 0; c < 8; c++) stage_row(src[c], stage_lds + (uint32_t)c * 256u);
                 }
             }
             if (st == ST_FETCH && exhausted && sg_cnt == 0) st = ST_DONE;
