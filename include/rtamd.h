@@ -255,9 +255,10 @@ enum rtamd_option {
     RTAMD_OPT_MAX_PATHS = 1,    /* pixels processed per wavefront chunk */
     RTAMD_OPT_LDS_SCENE = 2,    /* 1 (default): stage small meshes in LDS; 0: always read through L2 */
     RTAMD_OPT_SCHEDULER = 3,    /* batch trace entry points: 1 (default) persistent phase-voting kernel, 0 plain nested loops */
-    RTAMD_OPT_CHUNK = 4,        /* rays a wave dequeues per queue-head atomic (power of two, 64..4096) */
-    RTAMD_OPT_BLOCKS_PER_CU = 5,/* persistent 512-thread blocks per CU (1..8) */
-    RTAMD_OPT_STREAMS = 6       /* render: pixel groups in flight at once, each on its own HIP stream (1..8, default 4) */
+    RTAMD_OPT_CHUNK = 4,        /* rays a wave claims per queue-head atomic (power of two, 64..4096, default 64) */
+    RTAMD_OPT_BLOCKS_PER_CU = 5,/* persistent 512-thread blocks per CU (1..8, default 2) */
+    RTAMD_OPT_STREAMS = 6,      /* render: pixel groups in flight at once, each on its own HIP stream (1..8, default 1) */
+    RTAMD_OPT_STATIC_SHARE = 7  /* eighths (0..8, default 6) of a ray queue dealt to the waves up front; the rest is claimed dynamically */
 };
 int rtamd_set_option(rtamd_context* ctx, int option, int64_t value);
 /* Average duration (ms) and launch count of the closest-hit / any-hit trace kernels since the last

@@ -39,7 +39,7 @@ struct rtamd_context {
         hipEvent_t done = nullptr;
     };
     std::vector<Workspace> ws;
-    int n_streams = 4;
+    int n_streams = 1;
 
     // ray batch workspace of the host-pointer entry points
     void* batch_buf = nullptr;
@@ -301,6 +301,10 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
         case RTAMD_OPT_BLOCKS_PER_CU:
             if (value < 1 || value > 8) return fail(ctx, RTAMD_E_INVALID, "blocks per CU must be in [1, 8]");
             ctx->cfg.sched_blocks_per_cu = (int)value;
+            return RTAMD_OK;
+        case RTAMD_OPT_STATIC_SHARE:
+            if (value < 0 || value > 8) return fail(ctx, RTAMD_E_INVALID, "static share must be in [0, 8] eighths");
+            ctx->cfg.static_share = (int)value;
             return RTAMD_OK;
         case RTAMD_OPT_STREAMS:
             if (value < 1 || value > 8) return fail(ctx, RTAMD_E_INVALID, "streams must be in [1, 8]");

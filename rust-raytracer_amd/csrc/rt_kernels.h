@@ -67,8 +67,9 @@ struct CounterSlots {
 struct LaunchCfg {
     int num_cus = 256;
     int trace_blocks_per_cu = 4;   // grid-stride kernels
-    int sched_blocks_per_cu = 3;   // persistent scheduler kernels (512 threads each)
-    int chunk = 256;               // rays a wave dequeues per atomic
+    int sched_blocks_per_cu = 2;   // persistent scheduler kernels (512 threads each): what fits a CU (LDS, registers)
+    int chunk = 64;                // rays a wave claims per atomic from the shared part of a queue
+    int static_share = 6;          // eighths of a queue dealt to the waves without atomics (0..8)
     int use_lds = 1;
     int scheduler = 1;             // 1: persistent phase-voting scheduler, 0: plain nested-loop kernels (batch entry points only)
 };

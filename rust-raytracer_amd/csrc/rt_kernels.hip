@@ -152,7 +152,7 @@ struct BatchIO {
 
 template <int MESHLOC, bool TAB_LDS>
 __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
-    if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;  // enough earlier blocks exist to cover the batch
+    if (blockIdx.x >= (n + 63u) / 64u) return;  // not even the block's first wave has a batch (see trace_scheduler)
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
     LdsMesh lds;
     LdsTab ltab;
@@ -475,11 +475,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
         W.stats[0] += n_closest;
         W.stats[1] += n_any;
     }
-    if (blockIdx.x * (uint32_t)TRACE_BLOCK >= n) return;
-    // small queues: smaller chunks so that more waves share the work
-    uint32_t chunk = chunk_hint;
-    const uint32_t waves = gridDim.x * (TRACE_BLOCK / 64);
-    while (chunk > 64 && (n / chunk) < waves) chunk >>= 1;
+    if (blockIdx.x >= (n + 63u) / 64u) return;  // not even the block's first wave has a batch (see trace_scheduler)
+    const uint32_t chunk = chunk_hint;
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
     LdsMesh lds;
@@ -714,7 +711,7 @@ static inline uint32_t sched_chunk(const LaunchCfg& cfg, size_t n, uint32_t grid
     uint32_t chunk = (uint32_t)cfg.chunk;
     const size_t waves = (size_t)grid * (TRACE_BLOCK / 64);
     while (chunk > 64 && (n / chunk) < waves * 4) chunk >>= 1;
-    return chunk;
+    return chunk | ((uint32_t)cfg.static_share << 16);
 }
 
 hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st) {
@@ -767,7 +764,7 @@ hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hip
 hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
                              uint32_t head_idx, size_t upper, hipStream_t st) {
     uint32_t g = sched_grid(cfg, upper);
-    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk);
+    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16));
     return hipGetLastError();
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,

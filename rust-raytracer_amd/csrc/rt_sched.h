@@ -104,7 +104,8 @@ __device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t)__buil
 
 template <int MESHLOC, class Tab, class IO>
 __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
-                                                const uint32_t n_items, const uint32_t chunk, lds_u32* stage /* this wave's STAGE_WORDS */) {
+                                                const uint32_t n_items, const uint32_t chunk_and_share, lds_u32* stage /* this wave's STAGE_WORDS */) {
+    const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = chunk_and_share >> 16;  // rays per shared claim; eighths of the queue dealt statically
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
@@ -126,8 +127,23 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     uint32_t n_i = 0, n_n = 0, node_off = 0, tri_off = 0;
     uint32_t k_cur = 0, k_end = 0, oprim = 0;
     float ou = 0.f, ov = 0.f;
-    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
-    bool exhausted = false;                   // wave-uniform: the global queue has run dry
+    // Work distribution (all wave-uniform).  The first part of the queue is dealt out statically:
+    // wave w owns the 64-ray batches w, w + W, w + 2W, ... (W waves in the grid), spread over the
+    // whole queue so that every wave sees a mix of cheap and expensive rays, and needs no atomic.
+    // The rest is claimed `chunk` rays at a time from a shared head, which evens
+    // out what the static deal left unbalanced.  A returning atomic on one address completes at
+    // under 100 per microsecond on this GPU, so a launch must not start with one per wave.
+    // wave numbering runs over the blocks first, so that a short queue lands on every CU
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t n_batches = (n_items + 63u) >> 6;
+    uint32_t k_static = n_batches <= n_waves ? 1u : (share8 * n_batches) / (8u * n_waves);
+    if (k_static == 0u) k_static = 1u;
+    const uint64_t dyn_base64 = (uint64_t)k_static * n_waves * 64u;
+    const uint32_t dyn_base = dyn_base64 < n_items ? (uint32_t)dyn_base64 : n_items;
+    uint32_t ks = 0;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;                   // nothing is left for this wave to claim
 
     DIAG_DECL
     for (;;) {
@@ -316,8 +332,18 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             sg_pos += take;
             // staged batch used up: request the next one now, it is read in a later FETCH step
             if (sg_pos == sg_cnt && !exhausted) {
-                if (chunk_next == chunk_end) {
-                    const uint32_t base = claim_chunk(work_head, chunk);
+                if (chunk_next == chunk_end && ks < k_static) {  // next batch of the static deal
+                    const uint64_t b = ((uint64_t)wave_id + (uint64_t)ks * n_waves) * 64u;
+                    ks++;
+                    if (b < n_items) { chunk_next = (uint32_t)b; chunk_end = (n_items - chunk_next) < 64u ? n_items : chunk_next + 64u; }
+                    else ks = k_static;
+                }
+                if (chunk_next == chunk_end) {                   // shared remainder
+                    uint32_t base = n_items;
+                    if (dyn_base < n_items) {
+                        const uint32_t got = claim_chunk(work_head, chunk);
+                        base = got < n_items - dyn_base ? dyn_base + got : n_items;
+                    }
                     if (base >= n_items) {
                         exhausted = true;
                     } else {
