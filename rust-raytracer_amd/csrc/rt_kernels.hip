@@ -152,7 +152,10 @@ struct BatchIO {
 
 template <int MESHLOC, bool TAB_LDS>
 __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
-    if (blockIdx.x >= (n + 63u) / 64u) return;  // not even the block's first wave has a batch (see trace_scheduler)
+    {   // not even the block's first wave has a batch (see trace_scheduler)
+        const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64));
+        if (blockIdx.x >= (n + bs - 1u) / bs) return;
+    }
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
     LdsMesh lds;
     LdsTab ltab;
@@ -475,7 +478,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
         W.stats[0] += n_closest;
         W.stats[1] += n_any;
     }
-    if (blockIdx.x >= (n + 63u) / 64u) return;  // not even the block's first wave has a batch (see trace_scheduler)
+    {   // not even the block's first wave has a batch (see trace_scheduler)
+        const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64));
+        if (n == 0 || blockIdx.x >= (n + bs - 1u) / bs) return;
+    }
     const uint32_t chunk = chunk_hint;
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];

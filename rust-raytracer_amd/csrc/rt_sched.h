@@ -65,6 +65,15 @@ __device__ __forceinline__ uint32_t claim_chunk(uint32_t* work_head, uint32_t ch
     return __builtin_amdgcn_readfirstlane(base);
 }
 
+// Rays a wave takes per batch.  A queue that cannot give every wave of the grid a full batch of 64
+// is spread thinner instead: a wave's time on a batch grows with the number of different phase
+// steps its rays need, so 4096 waves with 8 rays each finish far sooner than 512 waves with 64.
+__device__ __forceinline__ uint32_t sched_batch_size(uint32_t n_items, uint32_t n_waves) {
+    if (n_items >= n_waves * 64u) return 64u;
+    const uint32_t bs = (n_items + n_waves - 1u) / n_waves;
+    return bs < 4u ? 4u : bs;
+}
+
 // Per-wave ray staging buffer in LDS: 8 rows (one per raw word of a ray) of 64 dwords.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 static constexpr uint32_t STAGE_WORDS = 8 * 64;
@@ -129,17 +138,19 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     float ou = 0.f, ov = 0.f;
     // Work distribution (all wave-uniform).  The first part of the queue is dealt out statically:
     // wave w owns the 64-ray batches w, w + W, w + 2W, ... (W waves in the grid), spread over the
-    // whole queue so that every wave sees a mix of cheap and expensive rays, and needs no atomic.
+    // whole queue so that every wave sees a mix of cheap and expensive rays, and needs no atomic
+    // (batches are shorter than 64 rays when the queue is short, see sched_batch_size).
     // The rest is claimed `chunk` rays at a time from a shared head, which evens
     // out what the static deal left unbalanced.  A returning atomic on one address completes at
     // under 100 per microsecond on this GPU, so a launch must not start with one per wave.
     // wave numbering runs over the blocks first, so that a short queue lands on every CU
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t n_batches = (n_items + 63u) >> 6;
+    const uint32_t bs = sched_batch_size(n_items, n_waves);   // 64 unless the queue is short
+    const uint32_t n_batches = (n_items + bs - 1u) / bs;
     uint32_t k_static = n_batches <= n_waves ? 1u : (share8 * n_batches) / (8u * n_waves);
     if (k_static == 0u) k_static = 1u;
-    const uint64_t dyn_base64 = (uint64_t)k_static * n_waves * 64u;
+    const uint64_t dyn_base64 = (uint64_t)k_static * n_waves * bs;
     const uint32_t dyn_base = dyn_base64 < n_items ? (uint32_t)dyn_base64 : n_items;
     uint32_t ks = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
@@ -333,9 +344,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             // staged batch used up: request the next one now, it is read in a later FETCH step
             if (sg_pos == sg_cnt && !exhausted) {
                 if (chunk_next == chunk_end && ks < k_static) {  // next batch of the static deal
-                    const uint64_t b = ((uint64_t)wave_id + (uint64_t)ks * n_waves) * 64u;
+                    const uint64_t b = ((uint64_t)wave_id + (uint64_t)ks * n_waves) * bs;
                     ks++;
-                    if (b < n_items) { chunk_next = (uint32_t)b; chunk_end = (n_items - chunk_next) < 64u ? n_items : chunk_next + 64u; }
+                    if (b < n_items) { chunk_next = (uint32_t)b; chunk_end = (n_items - chunk_next) < bs ? n_items : chunk_next + bs; }
                     else ks = k_static;
                 }
                 if (chunk_next == chunk_end) {                   // shared remainder
@@ -356,7 +367,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 if (!exhausted) {
                     const uint32_t left = chunk_end - chunk_next;
                     sg_base = chunk_next;
-                    sg_cnt = left < 64u ? left : 64u;
+                    sg_cnt = left < bs ? left : bs;
                     chunk_next += sg_cnt;
                     const void* src[8];
                     io.stage_addr(sg_base + (lane < sg_cnt ? lane : sg_cnt - 1u), src);
