@@ -106,7 +106,7 @@ def main():
     cam_wh, aa, max_depth, shadow_rays = WORKLOADS[args.workload]
     sky = rt.load_skybox(max_width=1024 if args.small_sky else None)
     scene = rt.Scene.main(sky=sky, cam=cam_wh).upload(local_rank)
-    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "max_paths": rt.OPT_MAX_PATHS, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE}
+    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "max_paths": rt.OPT_MAX_PATHS, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH}
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
         scene.set_option(opt_ids[k], int(v))

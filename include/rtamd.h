@@ -258,6 +258,7 @@ enum rtamd_option {
     RTAMD_OPT_CHUNK = 4,        /* rays a wave claims per queue-head atomic (power of two, 64..4096, default 64) */
     RTAMD_OPT_BLOCKS_PER_CU = 5,/* persistent 512-thread blocks per CU (1..8, default 2) */
     RTAMD_OPT_STREAMS = 6,      /* render: pixel groups in flight at once, each on its own HIP stream (1..8, default 1) */
+    RTAMD_OPT_MIN_BATCH = 8,    /* rays per wave below which a short ray queue is not spread over more waves (1..64, default 4) */
     RTAMD_OPT_STATIC_SHARE = 7  /* eighths (0..8, default 6) of a ray queue dealt to the waves up front; the rest is claimed dynamically */
 };
 int rtamd_set_option(rtamd_context* ctx, int option, int64_t value);

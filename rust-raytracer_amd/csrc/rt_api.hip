@@ -156,9 +156,7 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
         if ((rc = wave_alloc(ctx, ws, &W.q_slot[k], cap))) return rc;
         if ((rc = wave_alloc(ctx, ws, &W.q_ray[k], 6 * cap))) return rc;
     }
-    if ((rc = wave_alloc(ctx, ws, &W.h_obj, cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.h_prim, cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.h_f, 3 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.h_rec, 2 * cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.lit_slot, cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.lit_f, 6 * cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.smp, 4 * S * cap))) return rc;
@@ -305,6 +303,10 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
         case RTAMD_OPT_STATIC_SHARE:
             if (value < 0 || value > 8) return fail(ctx, RTAMD_E_INVALID, "static share must be in [0, 8] eighths");
             ctx->cfg.static_share = (int)value;
+            return RTAMD_OK;
+        case RTAMD_OPT_MIN_BATCH:
+            if (value < 1 || value > 64) return fail(ctx, RTAMD_E_INVALID, "min batch must be in [1, 64]");
+            ctx->cfg.min_batch = (int)value;
             return RTAMD_OK;
         case RTAMD_OPT_STREAMS:
             if (value < 1 || value > 8) return fail(ctx, RTAMD_E_INVALID, "streams must be in [1, 8]");

@@ -39,9 +39,10 @@ struct WaveBufs {
     uint32_t* q_slot[2];  // cap: pixel slot of the path
     float* q_ray[2];      // 6*cap: pos.xyz, dir.xyz
     // hit records of the current queue (what Geometry::hit found; the shade stage rebuilds pos / normal)
-    uint32_t* h_obj;      // cap: object index or MISS
-    uint32_t* h_prim;     // cap
-    float* h_f;           // 3*cap: t in the object's space, u, v
+    // One 32-byte record per path: {object index or MISS, primitive, t in the object's space, u} {v, -, -, -}.
+    // Rays of a wave finish in no particular order, so their results are scattered writes; as one
+    // record they touch one cache line per ray instead of five.
+    uint4* h_rec;         // 2*cap
     // lit queue: paths whose hit has a non-black diffuse colour
     uint32_t* lit_slot;   // cap
     float* lit_f;         // 6*cap: beta.xyz, diffuse.xyz
@@ -70,6 +71,7 @@ struct LaunchCfg {
     int sched_blocks_per_cu = 2;   // persistent scheduler kernels (512 threads each): what fits a CU (LDS, registers)
     int chunk = 64;                // rays a wave claims per atomic from the shared part of a queue
     int static_share = 6;          // eighths of a queue dealt to the waves without atomics (0..8)
+    int min_batch = 4;             // rays per wave below which a short queue is not spread any thinner (1..64)
     int use_lds = 1;
     int scheduler = 1;             // 1: persistent phase-voting scheduler, 0: plain nested-loop kernels (batch entry points only)
 };

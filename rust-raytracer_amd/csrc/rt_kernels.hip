@@ -153,16 +153,18 @@ struct BatchIO {
 template <int MESHLOC, bool TAB_LDS>
 __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
     {   // not even the block's first wave has a batch (see trace_scheduler)
-        const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64));
+        const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64), tune_min_batch(chunk));
         if (blockIdx.x >= (n + bs - 1u) / bs) return;
     }
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
+    __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][COOP_WORDS / 2];
     LdsMesh lds;
     LdsTab ltab;
     stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, stage);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage);
+    lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, stage, coop);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage, coop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,9 +434,7 @@ struct WaveIO {
     const float* q_ray;   // closest-hit ray queue of this bounce
     const float* a_ray;   // shadow-ray queue
     const uint32_t* a_vidx;
-    uint32_t* h_obj;
-    uint32_t* h_prim;
-    float* h_f;
+    uint4* h_rec;
     uint8_t* vis;
     uint32_t cap, any_cap;
     uint32_t n_closest;
@@ -458,10 +458,11 @@ struct WaveIO {
         tag = raw[7];
     }
     __device__ __forceinline__ void store_closest(uint32_t i, uint32_t, bool found, const Best& b, float) const {
-        h_obj[i] = found ? b.obj : MISS;
+        uint4* rec = h_rec + 2 * (size_t)i;
+        if (!found) rec[0].x = MISS;
         if (found) {
-            h_prim[i] = b.prim;
-            h_f[i] = b.t_local; h_f[i + cap] = b.u; h_f[i + 2 * cap] = b.v;
+            rec[0] = make_uint4(b.obj, b.prim, __float_as_uint(b.t_local), __float_as_uint(b.u));
+            rec[1].x = __float_as_uint(b.v);
         }
     }
     __device__ __forceinline__ void store_any(uint32_t, uint32_t tag, bool occluded) const { vis[tag] = occluded ? 1 : 0; }
@@ -479,18 +480,20 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
         W.stats[1] += n_any;
     }
     {   // not even the block's first wave has a batch (see trace_scheduler)
-        const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64));
+        const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64), tune_min_batch(chunk_hint));
         if (n == 0 || blockIdx.x >= (n + bs - 1u) / bs) return;
     }
     const uint32_t chunk = chunk_hint;
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
+    __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][COOP_WORDS / 2];
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
+    lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
     LdsMesh lds;
     LdsTab ltab;
     stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
-    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_obj, W.h_prim, W.h_f, W.vis, W.cap, W.any_cap, n_closest};
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage);
+    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_rec, W.vis, W.cap, W.any_cap, n_closest};
+    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
+    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,14 +529,15 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
             dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
             beta = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
             Best b;
-            b.obj = W.h_obj[i];
+            const uint4 rec0 = W.h_rec[2 * (size_t)i];
+            b.obj = rec0.x;
             if (b.obj == MISS) {  // integrator.rs:66
                 f3 c = beta * sky_color(S, dir);
                 W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
             } else {
                 hit = true;
-                b.prim = W.h_prim[i];
-                b.t_local = W.h_f[i]; b.u = W.h_f[i + cap]; b.v = W.h_f[i + 2 * cap];
+                b.prim = rec0.y;
+                b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = __uint_as_float(W.h_rec[2 * (size_t)i + 1].x);
                 f3 hp, hn;
                 float hu, hv;
                 reconstruct_hit(S, b, pos, dir, hp, hn, hu, hv);
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
 // Marks every queued path as a miss (max_depth = 0: integrate_recur returns the skybox at once).
 __global__ void k_mark_miss(WaveBufs W, uint32_t q_idx) {
     const uint32_t n = W.counts[q_idx];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W.h_obj[i] = MISS;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W.h_rec[2 * (size_t)i].x = MISS;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -717,7 +721,7 @@ static inline uint32_t sched_chunk(const LaunchCfg& cfg, size_t n, uint32_t grid
     uint32_t chunk = (uint32_t)cfg.chunk;
     const size_t waves = (size_t)grid * (TRACE_BLOCK / 64);
     while (chunk > 64 && (n / chunk) < waves * 4) chunk >>= 1;
-    return chunk | ((uint32_t)cfg.static_share << 16);
+    return chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20);
 }
 
 hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st) {
@@ -770,7 +774,7 @@ hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hip
 hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
                              uint32_t head_idx, size_t upper, hipStream_t st) {
     uint32_t g = sched_grid(cfg, upper);
-    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16));
+    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20));
     return hipGetLastError();
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,

@@ -45,16 +45,20 @@ static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
 // accumulated per wave and added to a global table when the wave ends.  Never compiled into librtamd.so.
 #ifdef RTAMD_DIAG
 __device__ unsigned long long g_diag[32];
-#define DIAG_DECL unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_steps[6] = {0, 0, 0, 0, 0, 0}, d_lanes[6] = {0, 0, 0, 0, 0, 0}; unsigned long long d_t0 = 0;
+#define DIAG_DECL unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_steps[6] = {0, 0, 0, 0, 0, 0}, d_lanes[6] = {0, 0, 0, 0, 0, 0}; unsigned long long d_t0 = 0; unsigned long long d_sub[4] = {0, 0, 0, 0}, d_subn[4] = {0, 0, 0, 0};
 #define DIAG_TOP d_t0 = __builtin_amdgcn_s_memtime();
 #define DIAG_STEP(ph, c) { d_steps[ph] += 1; d_lanes[ph] += (c); }
 #define DIAG_END(ph) { d_cyc[ph] += __builtin_amdgcn_s_memtime() - d_t0; }
-#define DIAG_FLUSH if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
+#define DIAG_SUB_BEGIN unsigned long long d_s0 = __builtin_amdgcn_s_memtime();
+#define DIAG_SUB_END(slot) { d_sub[slot] += __builtin_amdgcn_s_memtime() - d_s0; d_subn[slot] += 1; }
+#define DIAG_FLUSH if (lane == 0) { for (int q = 0; q < 4; q++) { atomicAdd(&g_diag[15 + 2 * q], d_sub[q]); atomicAdd(&g_diag[16 + 2 * q], d_subn[q]); } } if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
 #else
 #define DIAG_DECL
 #define DIAG_TOP
 #define DIAG_STEP(ph, c)
 #define DIAG_END(ph)
+#define DIAG_SUB_BEGIN
+#define DIAG_SUB_END(slot)
 #define DIAG_FLUSH
 #endif
 
@@ -68,11 +72,14 @@ __device__ __forceinline__ uint32_t claim_chunk(uint32_t* work_head, uint32_t ch
 // Rays a wave takes per batch.  A queue that cannot give every wave of the grid a full batch of 64
 // is spread thinner instead: a wave's time on a batch grows with the number of different phase
 // steps its rays need, so 4096 waves with 8 rays each finish far sooner than 512 waves with 64.
-__device__ __forceinline__ uint32_t sched_batch_size(uint32_t n_items, uint32_t n_waves) {
+__device__ __forceinline__ uint32_t sched_batch_size(uint32_t n_items, uint32_t n_waves, uint32_t min_batch) {
     if (n_items >= n_waves * 64u) return 64u;
     const uint32_t bs = (n_items + n_waves - 1u) / n_waves;
-    return bs < 4u ? 4u : bs;
+    return bs < min_batch ? min_batch : bs;
 }
+// The scheduler's tuning word: rays per shared claim (bits 0-15), eighths of the queue dealt
+// statically (16-19), smallest batch (20-27).
+__device__ __forceinline__ uint32_t tune_min_batch(uint32_t tune) { const uint32_t m = (tune >> 20) & 0xFFu; return m < 1u ? 1u : (m > 64u ? 64u : m); }
 
 // Per-wave ray staging buffer in LDS: 8 rows (one per raw word of a ray) of 64 dwords.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -111,10 +118,44 @@ enum : uint32_t {
 };
 __device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t)__builtin_popcountll(__ballot(p)); }
 
+// Inclusive wave64 scans on the VALU's lane-crossing paths (no LDS round trips): four row_shr steps
+// scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals across.  Must run with
+// all 64 lanes enabled; lanes that do not take part contribute the identity (0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+    x += dpp_or_zero<0x111, 0xF>(x);
+    x += dpp_or_zero<0x112, 0xF>(x);
+    x += dpp_or_zero<0x114, 0xF>(x);
+    x += dpp_or_zero<0x118, 0xF>(x);
+    x += dpp_or_zero<0x142, 0xA>(x);
+    x += dpp_or_zero<0x143, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+    x = max(x, dpp_or_zero<0x111, 0xF>(x));
+    x = max(x, dpp_or_zero<0x112, 0xF>(x));
+    x = max(x, dpp_or_zero<0x114, 0xF>(x));
+    x = max(x, dpp_or_zero<0x118, 0xF>(x));
+    x = max(x, dpp_or_zero<0x142, 0xA>(x));
+    x = max(x, dpp_or_zero<0x143, 0xC>(x));
+    return x;
+}
+__device__ __forceinline__ uint32_t lane_pull(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+__device__ __forceinline__ float lane_pull(uint32_t src_lane, float v) { return __uint_as_float(lane_pull(src_lane, __float_as_uint(v))); }
+
+// Per-wave LDS scratch of the cooperative triangle phase: owner marks (64 words), the winning key of
+// every owner lane (64 x 64 bit) and the winner's t, u, v (3 x 64 words).
+static constexpr uint32_t COOP_WORDS = 64 + 128 + 192;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+
 template <int MESHLOC, class Tab, class IO>
 __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
-                                                const uint32_t n_items, const uint32_t chunk_and_share, lds_u32* stage /* this wave's STAGE_WORDS */) {
-    const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = chunk_and_share >> 16;  // rays per shared claim; eighths of the queue dealt statically
+                                                const uint32_t n_items, const uint32_t chunk_and_share, lds_u32* stage /* this wave's STAGE_WORDS */,
+                                                lds_u32* coop /* this wave's COOP_WORDS */) {
+    const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = (chunk_and_share >> 16) & 0xFu;
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
@@ -146,7 +187,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     // wave numbering runs over the blocks first, so that a short queue lands on every CU
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * gridDim.x + blockIdx.x);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t bs = sched_batch_size(n_items, n_waves);   // 64 unless the queue is short
+    const uint32_t bs = sched_batch_size(n_items, n_waves, tune_min_batch(chunk_and_share));   // 64 unless the queue is short
     const uint32_t n_batches = (n_items + bs - 1u) / bs;
     uint32_t k_static = n_batches <= n_waves ? 1u : (share8 * n_batches) / (8u * n_waves);
     if (k_static == 0u) k_static = 1u;
@@ -175,26 +216,77 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t phase = key & 7u;
 
         if (phase == ST_TRI) {
-          // stay in the phase while at least STAY_NUM/STAY_DEN of the lanes that entered it still need it:
-          // one ballot per step instead of a full vote
-          for (uint32_t c = c_tri; c * STAY_DEN >= c_tri * STAY_NUM && c > 0; c = wave_count(st == ST_TRI)) {
-            DIAG_STEP(ST_TRI, c)
-            if (st == ST_TRI) {
+          // Cooperative triangle phase.  A leaf of the reference's trees holds many triangles (7-30 in
+          // the bunny), and the lanes waiting here are a minority of the wave, so one lane per ray
+          // would test them one by one with most of the wave idle.  Instead the pending (ray, triangle)
+          // pairs of all waiting lanes are laid out in one list and every lane of the wave tests one
+          // pair per round.  The reference walks a leaf in order, replacing the hit whenever
+          // t <= t_max (mesh.rs:130): the outcome is the smallest accepted t, the LAST triangle among
+          // equal t.  The same outcome comes from testing every pair against the t_max of the round's
+          // start and taking the minimum of (t, -index) per ray, done with a 64-bit LDS atomic min.
+          // volatile: the lanes talk to each other through these arrays; to the compiler every lane is a
+          // thread of its own, and it would otherwise forward a lane's own store to its later load
+          volatile lds_u32* mark = coop;
+          volatile lds_u64* slot = (volatile lds_u64*)(coop + 64);
+          volatile lds_u32* pay = coop + 192;
+          for (uint32_t round = 0;; round++) {
+            const bool is_tri = st == ST_TRI;
+            const uint32_t cnt = is_tri ? k_end - k_cur : 0u;
+            const uint32_t incl = wave_scan_add(cnt);
+            const uint32_t off = incl - cnt;                                   // first pair of this lane's leaf
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            const uint32_t c = wave_count(is_tri);
+            if (c == 0u || (round > 0u && total < 32u && c * STAY_DEN < c_tri * STAY_NUM)) break;
+            DIAG_STEP(ST_TRI, (total < 64u ? total : 64u))
+            // who owns pair p = lane: owners mark the first pair they own, a max-scan spreads the mark
+            mark[lane] = 0u;
+            slot[lane] = ~0ull;
+            if (is_tri && off < 64u) mark[off] = lane + 1u;
+            const uint32_t owner1 = wave_scan_max(mark[lane]);
+            const bool valid = lane < total;
+            const uint32_t o = valid ? owner1 - 1u : 0u;
+            // the owner's ray and leaf position
+            const uint32_t k = lane_pull(o, k_cur - off) + lane;
+            const f3 p_pos = mk(lane_pull(o, opos.x), lane_pull(o, opos.y), lane_pull(o, opos.z));
+            const f3 p_dir = mk(lane_pull(o, odir.x), lane_pull(o, odir.y), lane_pull(o, odir.z));
+            const float p_tmax = lane_pull(o, otmax);
+            bool p_lds = MESHLOC == MESH_LDS;
+            uint32_t p_tri_off = 0;
+            if (MESHLOC != MESH_LDS) {
+                p_tri_off = lane_pull(o, tri_off);
+                if (MESHLOC == MESH_MIXED) p_lds = (lane_pull(o, fl) & F_MLDS) != 0u;
+            }
+            float t = 0.f, u = 0.f, v = 0.f;
+            bool hit = false;
+            if (valid) {
                 float4 q0, q1, q2;
-                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && (fl & F_MLDS))) {
-                    lds_float4* tp = lds.tris + 3 * k_cur;
+                if (p_lds) {
+                    lds_float4* tp = lds.tris + 3 * k;
                     q0 = lds_load4(tp); q1 = lds_load4(tp + 1); q2 = lds_load4(tp + 2);
                 } else {
-                    const float4* tp = S.tris + 3 * ((size_t)tri_off + k_cur);
+                    const float4* tp = S.tris + 3 * ((size_t)p_tri_off + k);
                     q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
                 }
-                float t, u, v;
-                const bool hit = tri_test(q0, q1, q2, opos, odir, otmax, t, u, v);
+                hit = tri_test(q0, q1, q2, p_pos, p_dir, p_tmax, t, u, v);
+            }
+            // accepted t is >= 0 (or -0): its bit pattern orders like its value once -0 is folded onto +0
+            const uint32_t t_key = (t == 0.0f) ? 0u : __float_as_uint(t);
+            const unsigned long long my_key = ((unsigned long long)t_key << 32) | (unsigned long long)(0xFFFFFFFFu - k);
+            if (hit) __hip_atomic_fetch_min((lds_u64*)(coop + 64) + o, my_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (hit && slot[o] == my_key) { pay[o] = __float_as_uint(t); pay[64 + o] = __float_as_uint(u); pay[128 + o] = __float_as_uint(v); }
+            // owners: take the result, advance in the leaf
+            const uint32_t lim = off < 64u ? off : 64u, lim2 = (off + cnt) < 64u ? off + cnt : 64u;
+            const uint32_t served = lim2 - lim;
+            if (is_tri && served > 0u) {
+                const unsigned long long res = slot[lane];
+                const bool found = res != ~0ull;
                 const bool is_any = (fl & F_ANY) != 0u;
-                const bool hit_c = hit && !is_any, hit_a = hit && is_any;
-                // closest: a later triangle with t <= t_max replaces the earlier one (mesh.rs:130)
-                otmax = hit_c ? t : otmax; oprim = hit_c ? k_cur : oprim; ou = hit_c ? u : ou; ov = hit_c ? v : ov;
-                k_cur++;
+                const bool hit_c = found && !is_any, hit_a = found && is_any;
+                if (hit_c) {
+                    otmax = __uint_as_float(pay[lane]); ou = __uint_as_float(pay[64 + lane]); ov = __uint_as_float(pay[128 + lane]);
+                    oprim = 0xFFFFFFFFu - (uint32_t)res;
+                }
+                k_cur += served;
                 const bool leaf_done = k_cur >= k_end;          // leaf done: i += 1 (bvh.rs:245)
                 n_i += leaf_done ? 1u : 0u;
                 const bool mesh_done = leaf_done && n_i >= n_n;
@@ -321,15 +413,19 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             const bool got = want && rank < take;
             uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (take > 0) {
+                { DIAG_SUB_BEGIN
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the batch was requested in an earlier FETCH step
+                DIAG_SUB_END(0) }
                 const uint32_t src = (sg_pos + rank) & 63u;
 #pragma unroll
                 for (int c = 0; c < 8; c++) raw[c] = stage[c * 64 + src];
             }
+            { DIAG_SUB_BEGIN
             if (want && (fl & F_HAVE)) {
                 if (fl & F_ANY) io.store_any(ridx, rtag, (fl & F_OCC) != 0u);
                 else io.store_closest(ridx, rtag, best.obj != MISS, best, wtmax);
             }
+            DIAG_SUB_END(2) }
             fl &= want ? ~F_HAVE : ~0u;
             if (got) {
                 bool any;
@@ -352,7 +448,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 if (chunk_next == chunk_end) {                   // shared remainder
                     uint32_t base = n_items;
                     if (dyn_base < n_items) {
+                        DIAG_SUB_BEGIN
                         const uint32_t got = claim_chunk(work_head, chunk);
+                        DIAG_SUB_END(1)
                         base = got < n_items - dyn_base ? dyn_base + got : n_items;
                     }
                     if (base >= n_items) {

@@ -27,7 +27,7 @@ def main():
     rt = entry.load_package()
     w, h = map(int, args.cam.split("x"))
     scene = rt.Scene.main(sky=rt.load_skybox(max_width=2048), cam=(w, h)).upload(0)
-    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE}
+    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH}
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
         scene.set_option(opt_ids[k], int(v))
@@ -47,6 +47,10 @@ def main():
             if steps:
                 print(f"  {name:6s} cycles {100 * cyc / total:5.1f}%  steps {int(steps):>12d}  lanes/step {lanes / steps:5.1f}  "
                       f"cycles/step {cyc / steps:7.1f}  lane-steps/ray {lanes / rays:6.2f}")
+        sub = np.array(list(buf), dtype=np.float64)[15:23].reshape(4, 2)
+        for name, (cyc, cnt) in zip(("fetch: wait for staged batch", "fetch: queue-head atomic", "fetch: result stores", "-"), sub):
+            if cnt:
+                print(f"  {name:30s} {100 * cyc / total:5.1f}% of cycles  n {int(cnt):>10d}  cycles each {cyc / cnt:8.1f}")
 
 
 if __name__ == "__main__":
