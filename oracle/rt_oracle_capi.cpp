@@ -192,6 +192,52 @@ void* orc_scene_grid(const char* ply_path, int nx, int ny, const uint8_t* sky_rg
     return s;
 }
 
+// Synthetic: a heightfield mesh of n x n cells over [-6,6]^2 (vertex heights 0.6 * uniform from splitmix64(seed), drawn
+// row by row; two triangles per cell; in every cell with (ix + iy) % 7 == 0 the first triangle is listed twice, so
+// that leaves hold coplanar duplicates), Lambertian, translated to z = -1; with_bunny != 0 adds the reference scene's
+// scaled and rotated mesh (Transparent) and a copy at y + 2.5 (Metal) in front of it; a glossy floor cuboid below.
+// The heightfield comes first in the root list, i.e. it is mesh 0 of the flattened scene.
+void* orc_scene_terrain(const char* ply_path, int n, uint64_t seed, int with_bunny, const uint8_t* sky_rgb, int sky_w, int sky_h,
+                        int cam_w, int cam_h) {
+    auto* s = new OrcScene();
+    SplitMix64 g{seed};
+    std::vector<V3> tv;
+    std::vector<std::array<uint32_t, 3>> tf;
+    const float cell = 12.0f / (float)n;
+    for (int iy = 0; iy <= n; iy++)
+        for (int ix = 0; ix <= n; ix++) tv.push_back(V3(-6.0f + cell * (float)ix, -6.0f + cell * (float)iy, 0.6f * g.uniform()));
+    for (int iy = 0; iy < n; iy++)
+        for (int ix = 0; ix < n; ix++) {
+            uint32_t a = (uint32_t)(iy * (n + 1) + ix), b = a + 1, c = a + (uint32_t)(n + 1), d = c + 1;
+            tf.push_back({a, b, d});
+            if ((ix + iy) % 7 == 0) tf.push_back({a, b, d});
+            tf.push_back({a, d, c});
+        }
+    auto terrain = Mesh::from_vertices(tv, tf);
+    s->mesh = terrain;
+    std::vector<std::shared_ptr<Object>> objs;
+    objs.push_back(std::make_shared<Object>(std::make_shared<Translate>(terrain, V3::fill(0.0f) + V3(0.0f, 0.0f, -1.0f)), mat_lambert(V3(1.f, 1.f, 1.f))));
+    if (with_bunny) {
+        std::vector<V3> verts;
+        std::vector<std::array<uint32_t, 3>> faces;
+        if (!load_ply(ply_path, verts, faces, s->error)) { fprintf(stderr, "orc: %s\n", s->error.c_str()); delete s; return nullptr; }
+        auto bunny = Mesh::from_vertices(verts, faces);
+        GeomPtr tmesh = TransformBuilder(bunny).scale(20.0f).rotate(V3(1.f, 0.f, 0.f), 90.0f * (PI_F / 180.0f)).build();
+        objs.push_back(std::make_shared<Object>(tmesh, mat_transparent(1.0f / 0.6f)));
+        objs.push_back(std::make_shared<Object>(std::make_shared<Translate>(tmesh, V3::fill(0.0f) + V3(0.0f, 2.5f, 0.0f)), mat_metal()));
+    }
+    objs.push_back(std::make_shared<Object>(std::make_shared<Cuboid>(V3(-7.0f, -7.0f, -1.5f), V3(7.0f, 7.0f, -2.5f)), mat_glossy(1e3f, 0.3f, V3(1.f, 1.f, 1.f))));
+    auto list = std::make_shared<GeometryList>();
+    for (auto& o : objs) list->items.push_back(o);
+    finalize_object_ids(s, objs);
+    s->cam_pos = V3(-8.0f, -8.0f, 5.0f); s->cam_focus = V3(0.0f, 0.0f, 0.0f); s->cam_up = -V3(0.f, 0.f, 1.f);
+    s->make_camera((size_t)cam_w, (size_t)cam_h);
+    s->scene.root = list;
+    s->scene.skybox = make_sky(sky_rgb, sky_w, sky_h);
+    s->scene.lights = main_lights();
+    return s;
+}
+
 void orc_scene_free(void* p) { delete (OrcScene*)p; }
 
 // Re-run the camera script (Camera::new(w,h).position(..).look_at(..)) at another resolution.

@@ -120,6 +120,8 @@ def host_lib():
         _host.rth_scene_main.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_spheres.restype = C.c_void_p
         _host.rth_scene_spheres.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _host.rth_scene_terrain.restype = C.c_void_p
+        _host.rth_scene_terrain.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_grid.restype = C.c_void_p
         _host.rth_scene_grid.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_free.argtypes = [C.c_void_p]
@@ -182,6 +184,12 @@ class Scene:
     def grid(cls, nx, ny, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
         sky, p, w, h = cls._sky_args(sky)
         return cls(host_lib().rth_scene_grid(ply.encode(), nx, ny, p, w, h, cam[0], cam[1]), sky)
+
+    @classmethod
+    def terrain(cls, n, seed=1, with_bunny=True, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
+        """Heightfield mesh of n x n cells (with coplanar duplicate triangles), optionally with two bunny instances."""
+        sky, p, w, h = cls._sky_args(sky)
+        return cls(host_lib().rth_scene_terrain(ply.encode(), n, seed, int(with_bunny), p, w, h, cam[0], cam[1]), sky)
 
     def __del__(self):
         try:

@@ -288,5 +288,6 @@ Scene scene_main(const std::string& ply_path, std::shared_ptr<const Image> skybo
 // Synthetic scenes of the larger benchmark configurations (generator: splitmix64, see rt_scenes.cpp).
 Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
+Scene scene_terrain(const std::string& ply_path, int n, uint64_t seed, bool with_bunny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 
 }  // namespace rth

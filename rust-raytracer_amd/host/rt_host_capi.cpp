@@ -43,6 +43,9 @@ void* rth_scene_spheres(int n, uint64_t seed, const uint8_t* sky, int sw, int sh
 void* rth_scene_grid(const char* ply, int nx, int ny, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
 }
+void* rth_scene_terrain(const char* ply, int n, uint64_t seed, int with_bunny, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
+    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_terrain(ply, n, seed, with_bunny != 0, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
+}
 void rth_scene_free(void* p) { delete (Handle*)p; }
 
 // Camera::new(w, h).position(pos).look_towards(dir, up) at another resolution, keeping the pose:

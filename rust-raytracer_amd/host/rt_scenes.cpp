@@ -108,4 +108,43 @@ Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<co
     return scene;
 }
 
+// Heightfield of n x n cells over [-6,6]^2 (vertex heights 0.6 * uniform, drawn row by row; two triangles per cell;
+// every cell with (ix + iy) % 7 == 0 lists its first triangle twice: coplanar duplicates inside a leaf), Lambertian,
+// translated to z = -1; with_bunny adds the reference scene's mesh (Transparent) and a copy at y + 2.5 (Metal);
+// glossy floor cuboid below.  A scene with two different meshes, one of them as large as n asks for.
+Scene scene_terrain(const std::string& ply_path, int n, uint64_t seed, bool with_bunny, std::shared_ptr<const Image> skybox,
+                    size_t cam_w, size_t cam_h) {
+    SplitMix64 g{seed};
+    std::vector<Vec3D> tv;
+    std::vector<std::array<uint32_t, 3>> tf;
+    const float cell = 12.0f / (float)n;
+    for (int iy = 0; iy <= n; iy++)
+        for (int ix = 0; ix <= n; ix++) tv.push_back(Vec3D(-6.0f + cell * (float)ix, -6.0f + cell * (float)iy, 0.6f * g.uniform()));
+    for (int iy = 0; iy < n; iy++)
+        for (int ix = 0; ix < n; ix++) {
+            uint32_t a = (uint32_t)(iy * (n + 1) + ix), b = a + 1, c = a + (uint32_t)(n + 1), d = c + 1;
+            tf.push_back({a, b, d});
+            if ((ix + iy) % 7 == 0) tf.push_back({a, b, d});
+            tf.push_back({a, d, c});
+        }
+    auto terrain = Mesh::from_vertices(tv, tf);
+    std::vector<Object> list;
+    list.push_back(Object::with_material(Translate::make(terrain)->translate(Vec3D(0.0f, 0.0f, -1.0f)), Lambartian(COLOR_WHITE)));
+    if (with_bunny) {
+        auto mesh = loader::load_ply_as_mesh(ply_path);
+        GeomPtr tmesh = Transform::make(mesh)->scale(20.0f)->rotate_x(to_radians(90.0f));
+        list.push_back(Object::with_material(tmesh, Transparent(1.0f / 0.6f)));
+        list.push_back(Object::with_material(Translate::make(tmesh)->translate_y(2.5f), Metal()));
+    }
+    list.push_back(Object::with_material(Cuboid::make(vec3d(-7.0f, -7.0f, -1.5f), vec3d(7.0f, 7.0f, -2.5f)), Glossy(1e3f, 0.3f, COLOR_WHITE)));
+    Camera cam(cam_w, cam_h);
+    cam.position(Vec3D(-8.0f, -8.0f, 5.0f)).look_at(Vec3D(0.0f, 0.0f, 0.0f), -Vec3D::z_axis());
+    Scene scene;
+    scene.root = GeometryList::from_vec(list);
+    scene.camera = cam;
+    scene.skybox = skybox;
+    scene.lights = main_lights();
+    return scene;
+}
+
 }  // namespace rth

@@ -42,6 +42,8 @@ def lib():
         _lib.orc_scene_main.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_spheres.restype = C.c_void_p
         _lib.orc_scene_spheres.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.orc_scene_terrain.restype = C.c_void_p
+        _lib.orc_scene_terrain.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_grid.restype = C.c_void_p
         _lib.orc_scene_grid.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_free.argtypes = [C.c_void_p]
@@ -111,6 +113,12 @@ class OracleScene:
     def grid(cls, nx, ny, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
         sky = procedural_sky() if sky is None else np.ascontiguousarray(sky, dtype=np.uint8)
         hnd = lib().orc_scene_grid(ply.encode(), nx, ny, sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
+        return cls(hnd, sky)
+
+    @classmethod
+    def terrain(cls, n, seed=1, with_bunny=True, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
+        sky = procedural_sky() if sky is None else np.ascontiguousarray(sky, dtype=np.uint8)
+        hnd = lib().orc_scene_terrain(ply.encode(), n, seed, int(with_bunny), sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
         return cls(hnd, sky)
 
     def __del__(self):

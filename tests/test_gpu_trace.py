@@ -153,6 +153,48 @@ def test_instanced_grid_scene(rt, ol, sky):
     assert np.array_equal(gpu.trace_any(rays), ref)
 
 
+@pytest.mark.parametrize("n,with_bunny", [(6, True), (70, True), (70, False)])
+def test_two_mesh_scene_with_coplanar_duplicates(rt, ol, sky, n, with_bunny):
+    """Heightfield + bunny: n = 6 keeps the heightfield in LDS and the bunny in global memory, n = 70 the other way
+    round, without the bunny nothing fits LDS.  One cell in seven lists a triangle twice: the later copy must win."""
+    cam = (320, 240)
+    gpu = rt.Scene.terrain(n, seed=3, with_bunny=with_bunny, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.terrain(n, seed=3, with_bunny=with_bunny, sky=sky, cam=cam)
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    ref = cpu.trace_closest(rays)
+    hits = check_closest(rt, gpu.trace_closest(rays), ref)
+    assert hits > 0.4 * rays.shape[1]
+    # straight down onto the heightfield: every cell centre, duplicated cells included
+    xs = (np.arange(n) + 0.3) * (12.0 / n) - 6.0
+    gx, gy = np.meshgrid(xs, xs + 0.1 * (12.0 / n))
+    down = np.zeros((7, gx.size), np.float32)
+    down[0], down[1], down[2] = gx.ravel(), gy.ravel(), 3.0
+    down[5] = -1.0
+    down[6] = 1e12
+    ref = cpu.trace_closest(down)
+    check_closest(rt, gpu.trace_closest(down), ref)
+    on_field = ref["obj"] == 0
+    assert on_field.mean() > 0.6
+    rays = random_rays(100_000, seed=31, center=(0, 0, 0.5), radius=8.0)
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    rays[6] = np.random.default_rng(8).uniform(0.0, 12.0, rays.shape[1]).astype(np.float32)
+    occ, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), occ)
+    gpu.set_option(rt.OPT_LDS_SCENE, 0)
+    check_closest(rt, gpu.trace_closest(down), ref)
+
+
+def test_full_4k_primary_batch(rt, ol, sky):
+    """The 3840x2160 primary-ray configuration at full size: all 8 294 400 rays against the oracle."""
+    cam = (3840, 2160)
+    gpu = rt.Scene.main(sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.main(sky=sky, cam=cam)
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    assert rays.shape[1] == 8_294_400
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays, threads=16))
+    assert 0.2 * rays.shape[1] < hits < 0.9 * rays.shape[1]
+
+
 def test_errors_are_reported_not_fatal(rt, sky):
     s = rt.Scene.main(sky=sky, cam=(64, 64))
     with pytest.raises(rt.RtamdError):

@@ -51,6 +51,15 @@ def test_host_trees_and_camera_match_oracle(rt, ol, sky):
         assert np.array_equal(gn, cn) and np.array_equal(gs, cs)
 
 
+def test_terrain_scene_host_matches_oracle(rt, ol, sky):
+    for n, wb in ((6, True), (40, False)):
+        g, c = rt.Scene.terrain(n, seed=3, with_bunny=wb, sky=sky, cam=(64, 48)), ol.OracleScene.terrain(n, seed=3, with_bunny=wb, sky=sky, cam=(64, 48))
+        gn, go, gs = g.tree(0)
+        cn, co, cs = c.bvh(0)
+        assert np.array_equal(gn, cn) and np.array_equal(go, co) and np.array_equal(gs, cs)
+        assert gs[0] == 2 * n * n + sum(1 for iy in range(n) for ix in range(n) if (ix + iy) % 7 == 0)  # duplicates are kept
+
+
 def test_no_cpu_fallback(rt, sky):
     """Without an uploaded GPU context every trace / render call must raise, never compute on the host."""
     s = rt.Scene.main(sky=sky, cam=(32, 32))
