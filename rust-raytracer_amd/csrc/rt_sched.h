@@ -197,6 +197,29 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;                   // nothing is left for this wave to claim
 
+    // One node of the current mesh tree (bvh.rs:227-252): visit test, then into the leaf, on to the next
+    // node, or along the skip link.  Used by the NODE phase and, for a mesh's root, by the OBJ phase.
+    auto node_step = [&]() {
+        float4 n0, n1;
+        if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && (fl & F_MLDS))) {
+            lds_float4* np = lds.nodes + 2 * n_i;
+            n0 = lds_load4(np); n1 = lds_load4(np + 1);
+        } else {
+            const float4* np = S.nodes + 2 * ((size_t)node_off + n_i);
+            n0 = np[0]; n1 = np[1];
+        }
+        const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
+        const bool leaf = (A & LEAF_BIT) != 0u;
+        const uint32_t first = A & ~LEAF_BIT;
+        const bool pass = node_passes(n0, n1, opos, oinv, signbit32(oinv.x), signbit32(oinv.y), signbit32(oinv.z), otmax);
+        const bool enter = pass && leaf && first < B;
+        k_cur = enter ? first : k_cur; k_end = enter ? B : k_end;
+        n_i = enter ? n_i : ((pass || leaf) ? n_i + 1 : A);   // skip link on a failed inner node
+        const bool mesh_done = !enter && n_i >= n_n;
+        fl |= mesh_done ? F_PEND : 0u;
+        st = enter ? ST_TRI : (mesh_done ? ST_OBJ : ST_NODE);
+    };
+
     DIAG_DECL
     for (;;) {
         DIAG_TOP
@@ -297,26 +320,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         } else if (phase == ST_NODE) {
           for (uint32_t c = c_node; c * STAY_DEN >= c_node * STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
-            if (st == ST_NODE) {
-                float4 n0, n1;
-                if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && (fl & F_MLDS))) {
-                    lds_float4* np = lds.nodes + 2 * n_i;
-                    n0 = lds_load4(np); n1 = lds_load4(np + 1);
-                } else {
-                    const float4* np = S.nodes + 2 * ((size_t)node_off + n_i);
-                    n0 = np[0]; n1 = np[1];
-                }
-                const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
-                const bool leaf = (A & LEAF_BIT) != 0u;
-                const uint32_t first = A & ~LEAF_BIT;
-                const bool pass = node_passes(n0, n1, opos, oinv, signbit32(oinv.x), signbit32(oinv.y), signbit32(oinv.z), otmax);
-                const bool enter = pass && leaf && first < B;
-                k_cur = enter ? first : k_cur; k_end = enter ? B : k_end;
-                n_i = enter ? n_i : ((pass || leaf) ? n_i + 1 : A);   // skip link on a failed inner node
-                const bool mesh_done = !enter && n_i >= n_n;
-                fl |= mesh_done ? F_PEND : 0u;
-                st = enter ? ST_TRI : (mesh_done ? ST_OBJ : ST_NODE);
-            }
+            if (st == ST_NODE) node_step();
           }
         } else if (phase == ST_TNODE) {
           for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * STAY_NUM && c > 0; c = wave_count(st == ST_TNODE)) {
@@ -337,7 +341,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             }
           }
         } else if (phase == ST_OBJ) {
-            DIAG_STEP(ST_OBJ, c_obj)
+          // A lane stays in this phase across objects that end at once: a primitive that is not a mesh, or a mesh
+          // whose root box the ray misses (most instances, for most rays): its root is tested right here.
+          for (uint32_t c = c_obj; c * STAY_DEN >= c_obj * STAY_NUM && c > 0; c = wave_count(st == ST_OBJ)) {
+            DIAG_STEP(ST_OBJ, c)
             if (st == ST_OBJ) {
                 // (1) fold a finished mesh walk into the ray's closest hit (bvh.rs:262-264, transform.rs:107)
                 if ((fl & (F_PEND | F_FOUND)) == (F_PEND | F_FOUND)) {
@@ -384,7 +391,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
                         if (MESHLOC == MESH_MIXED) fl = (ob.geom_index == S.lds_mesh) ? (fl | F_MLDS) : (fl & ~F_MLDS);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
-                        if (n_n > 0) st = ST_NODE;
+                        if (n_n > 0) node_step();
                     } else {
                         float t = 0.0f;
                         bool hit;
@@ -402,6 +409,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     }
                 }
             }
+          }
         } else {  // ST_FETCH
             DIAG_STEP(ST_FETCH, c_fetch)
             const bool want = st == ST_FETCH;
