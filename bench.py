@@ -9,9 +9,11 @@ max_depth 5, shadow_rays 1, scatter_rays 1.  One step = one full frame through t
 (ray generation, closest-hit trace, shade, shadow trace, compaction), scene and skybox resident in HBM.
 Metric: Mrays/s = (closest-hit + any-hit rays traced) / wall time, whole job.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's 64x64 tiles are dealt round-robin
-to the ranks, every rank renders its tiles, and the framebuffer is gathered to rank 0 with one RCCL gather
-inside the timed region (strong scaling: the frame is fixed).
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame grows with N at the same camera, aspect
+ratio and samples per pixel (N x 1080x960 pixels: 1528x1358, 2160x1920, 3056x2715 for N = 2, 4, 8), its 64x64 tiles
+are dealt round-robin to the ranks, every rank renders its tiles, and the framebuffer is gathered to rank 0 with
+one RCCL gather inside the timed region.  Per-GPU work is fixed, so this is weak scaling: a 1080x960 frame cut in
+eight leaves each GPU launches of a few ten thousand rays, which measure launch latency rather than the path.
 """
 import argparse
 import json
@@ -94,18 +96,29 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the render path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RTAMD_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # the gather goes through host memory); the driver's runs use the default, RCCL with one GPU per rank.
+    backend = os.environ.get("RTAMD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     rt = entry.load_package()
     from rust_raytracer_amd import dist_tiles
 
     cam_wh, aa, max_depth, shadow_rays = WORKLOADS[args.workload]
+    base_wh = cam_wh
+    if world > 1:  # weak scaling: world x the pixels, same aspect ratio
+        w = int(round(cam_wh[0] * (world ** 0.5) / 8.0)) * 8
+        cam_wh = (w, int(round(world * cam_wh[0] * cam_wh[1] / w)))
     sky = rt.load_skybox(max_width=1024 if args.small_sky else None)
-    scene = rt.Scene.main(sky=sky, cam=cam_wh).upload(local_rank)
+    scene = rt.Scene.main(sky=sky, cam=cam_wh).upload(dev_index)
     opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "max_paths": rt.OPT_MAX_PATHS, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH}
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
@@ -141,13 +154,14 @@ def main():
     closest_per_step, any_per_step, paths_per_step = st["closest_rays"], st["any_rays"], st["paths"]
 
     if world > 1:
-        t = torch.tensor([elapsed, float(rays), float(closest_per_step), float(any_per_step)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(rays), float(closest_per_step), float(any_per_step), float(paths_per_step)], dtype=torch.float64,
+                         device=dev if backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         rays = float(t[1])
-        closest_per_step, any_per_step = float(t[2]), float(t[3])
+        closest_per_step, any_per_step, paths_per_step = float(t[2]), float(t[3]), float(t[4])
 
     # ---- rank 0, N = 1: roofline of the dominant kernel (HIP events on the kernels' own stream) + CPU baseline ----
     roofline = None
@@ -194,10 +208,11 @@ def main():
         line = {
             "metric": "Mrays/s (primary + diffuse bounce) on bunny BVH", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "width": W, "height": H, "spp": aa * aa, "max_depth": max_depth,
                        "shadow_rays": shadow_rays, "scatter_rays": 1, "tile": TILE,
                        "parallelism": f"tiles{world}" if world > 1 else "single",
+                       "frame_per_gpu": f"{base_wh[0]}x{base_wh[1]}",
                        "scene": "reference main.rs scene: bundled bunny.ply x3 instances + floor cuboid + skybox.jpg"},
             "rays_per_step": {"closest": closest_per_step, "any": any_per_step, "paths": paths_per_step},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -28,6 +28,8 @@ def gather_frame(tiles, w, h, tile_w, tile_h, rank, world, dst=0):
     tiles = tiles.reshape(-1, tile_h, tile_w, 3)
     assert tiles.shape[0] == owned_tile_count(n_tiles, rank, world)
     if world > 1:
+        if tiles.is_cuda and dist.get_backend() == "gloo":
+            tiles = tiles.cpu()  # gloo gathers host tensors only (rehearsal of the multi-rank path without one GPU per rank)
         if tiles.shape[0] < per_rank:
             pad = torch.zeros((per_rank - tiles.shape[0], tile_h, tile_w, 3), dtype=tiles.dtype, device=tiles.device)
             tiles = torch.cat([tiles, pad], dim=0)
