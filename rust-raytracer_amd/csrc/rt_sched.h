@@ -245,62 +245,65 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           // pairs of all waiting lanes are laid out in one list and every lane of the wave tests one
           // pair per round.  The reference walks a leaf in order, replacing the hit whenever
           // t <= t_max (mesh.rs:130): the outcome is the smallest accepted t, the LAST triangle among
-          // equal t.  The same outcome comes from testing every pair against the t_max of the round's
-          // start and taking the minimum of (t, -index) per ray, done with a 64-bit LDS atomic min.
+          // equal t.  The same outcome comes from testing every pair against the t_max the ray arrived
+          // with and taking the minimum of (t, -index) per ray, done with a 64-bit LDS atomic min.
           // volatile: the lanes talk to each other through these arrays; to the compiler every lane is a
           // thread of its own, and it would otherwise forward a lane's own store to its later load
           volatile lds_u32* mark = coop;
           volatile lds_u64* slot = (volatile lds_u64*)(coop + 64);
           volatile lds_u32* pay = coop + 192;
-          for (uint32_t round = 0;; round++) {
+          {
+            // every pair pending at this visit is tested against the t_max its ray arrived with; leaves that span
+            // rounds keep accumulating their minimum in the same LDS slot
             const bool is_tri = st == ST_TRI;
             const uint32_t cnt = is_tri ? k_end - k_cur : 0u;
             const uint32_t incl = wave_scan_add(cnt);
             const uint32_t off = incl - cnt;                                   // first pair of this lane's leaf
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-            const uint32_t c = wave_count(is_tri);
-            if (c == 0u || (round > 0u && total < 32u && c * STAY_DEN < c_tri * STAY_NUM)) break;
-            DIAG_STEP(ST_TRI, (total < 64u ? total : 64u))
-            // who owns pair p = lane: owners mark the first pair they own, a max-scan spreads the mark
-            mark[lane] = 0u;
+            const uint32_t kbase = k_cur - off;                                // triangle of pair p: kbase + p
             slot[lane] = ~0ull;
-            if (is_tri && off < 64u) mark[off] = lane + 1u;
-            const uint32_t owner1 = wave_scan_max(mark[lane]);
-            const bool valid = lane < total;
-            const uint32_t o = valid ? owner1 - 1u : 0u;
-            // the owner's ray and leaf position
-            const uint32_t k = lane_pull(o, k_cur - off) + lane;
-            const f3 p_pos = mk(lane_pull(o, opos.x), lane_pull(o, opos.y), lane_pull(o, opos.z));
-            const f3 p_dir = mk(lane_pull(o, odir.x), lane_pull(o, odir.y), lane_pull(o, odir.z));
-            const float p_tmax = lane_pull(o, otmax);
-            bool p_lds = MESHLOC == MESH_LDS;
-            uint32_t p_tri_off = 0;
-            if (MESHLOC != MESH_LDS) {
-                p_tri_off = lane_pull(o, tri_off);
-                if (MESHLOC == MESH_MIXED) p_lds = (lane_pull(o, fl) & F_MLDS) != 0u;
-            }
-            float t = 0.f, u = 0.f, v = 0.f;
-            bool hit = false;
-            if (valid) {
-                float4 q0, q1, q2;
-                if (p_lds) {
-                    lds_float4* tp = lds.tris + 3 * k;
-                    q0 = lds_load4(tp); q1 = lds_load4(tp + 1); q2 = lds_load4(tp + 2);
-                } else {
-                    const float4* tp = S.tris + 3 * ((size_t)p_tri_off + k);
-                    q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
+            for (uint32_t base = 0; base < total; base += 64u) {
+                DIAG_STEP(ST_TRI, (total - base < 64u ? total - base : 64u))
+                // who owns pair p = base + lane: owners mark their first pair of this round, a max-scan spreads the mark
+                mark[lane] = 0u;
+                const uint32_t lo = off > base ? off : base;
+                if (is_tri && lo < off + cnt && lo < base + 64u) mark[lo - base] = lane + 1u;
+                const uint32_t owner1 = wave_scan_max(mark[lane]);
+                const uint32_t p = base + lane;
+                const bool valid = p < total;
+                const uint32_t o = valid ? owner1 - 1u : 0u;
+                // the owner's ray and leaf position
+                const uint32_t k = lane_pull(o, kbase) + p;
+                const f3 p_pos = mk(lane_pull(o, opos.x), lane_pull(o, opos.y), lane_pull(o, opos.z));
+                const f3 p_dir = mk(lane_pull(o, odir.x), lane_pull(o, odir.y), lane_pull(o, odir.z));
+                const float p_tmax = lane_pull(o, otmax);
+                bool p_lds = MESHLOC == MESH_LDS;
+                uint32_t p_tri_off = 0;
+                if (MESHLOC != MESH_LDS) {
+                    p_tri_off = lane_pull(o, tri_off);
+                    if (MESHLOC == MESH_MIXED) p_lds = (lane_pull(o, fl) & F_MLDS) != 0u;
                 }
-                hit = tri_test(q0, q1, q2, p_pos, p_dir, p_tmax, t, u, v);
+                float t = 0.f, u = 0.f, v = 0.f;
+                bool hit = false;
+                if (valid) {
+                    float4 q0, q1, q2;
+                    if (p_lds) {
+                        lds_float4* tp = lds.tris + 3 * k;
+                        q0 = lds_load4(tp); q1 = lds_load4(tp + 1); q2 = lds_load4(tp + 2);
+                    } else {
+                        const float4* tp = S.tris + 3 * ((size_t)p_tri_off + k);
+                        q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
+                    }
+                    hit = tri_test(q0, q1, q2, p_pos, p_dir, p_tmax, t, u, v);
+                }
+                // accepted t is >= 0 (or -0): its bit pattern orders like its value once -0 is folded onto +0
+                const uint32_t t_key = (t == 0.0f) ? 0u : __float_as_uint(t);
+                const unsigned long long my_key = ((unsigned long long)t_key << 32) | (unsigned long long)(0xFFFFFFFFu - k);
+                if (hit) __hip_atomic_fetch_min((lds_u64*)(coop + 64) + o, my_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hit && slot[o] == my_key) { pay[o] = __float_as_uint(t); pay[64 + o] = __float_as_uint(u); pay[128 + o] = __float_as_uint(v); }
             }
-            // accepted t is >= 0 (or -0): its bit pattern orders like its value once -0 is folded onto +0
-            const uint32_t t_key = (t == 0.0f) ? 0u : __float_as_uint(t);
-            const unsigned long long my_key = ((unsigned long long)t_key << 32) | (unsigned long long)(0xFFFFFFFFu - k);
-            if (hit) __hip_atomic_fetch_min((lds_u64*)(coop + 64) + o, my_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (hit && slot[o] == my_key) { pay[o] = __float_as_uint(t); pay[64 + o] = __float_as_uint(u); pay[128 + o] = __float_as_uint(v); }
-            // owners: take the result, advance in the leaf
-            const uint32_t lim = off < 64u ? off : 64u, lim2 = (off + cnt) < 64u ? off + cnt : 64u;
-            const uint32_t served = lim2 - lim;
-            if (is_tri && served > 0u) {
+            // owners: take the result; the leaf is done: i += 1 (bvh.rs:245)
+            if (is_tri) {
                 const unsigned long long res = slot[lane];
                 const bool found = res != ~0ull;
                 const bool is_any = (fl & F_ANY) != 0u;
@@ -309,12 +312,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     otmax = __uint_as_float(pay[lane]); ou = __uint_as_float(pay[64 + lane]); ov = __uint_as_float(pay[128 + lane]);
                     oprim = 0xFFFFFFFFu - (uint32_t)res;
                 }
-                k_cur += served;
-                const bool leaf_done = k_cur >= k_end;          // leaf done: i += 1 (bvh.rs:245)
-                n_i += leaf_done ? 1u : 0u;
-                const bool mesh_done = leaf_done && n_i >= n_n;
+                k_cur = k_end;
+                n_i++;
+                const bool mesh_done = n_i >= n_n;
                 fl |= (hit_c ? F_FOUND : 0u) | (hit_a ? (F_OCC | F_HAVE) : 0u) | ((mesh_done && !hit_a) ? F_PEND : 0u);
-                st = hit_a ? ST_FETCH : (leaf_done ? (mesh_done ? ST_OBJ : ST_NODE) : ST_TRI);
+                st = hit_a ? ST_FETCH : (mesh_done ? ST_OBJ : ST_NODE);
             }
           }
         } else if (phase == ST_NODE) {
