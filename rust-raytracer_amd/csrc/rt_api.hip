@@ -2,6 +2,7 @@
 // Host side only: context, scene upload (reference layout -> device layout), launch sequencing.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -496,6 +497,14 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     }
     // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
+    // a root list of plain objects with consecutive indices is walked as one range, without reading the list
+    S.root_first = MISS;
+    if (sc->n_root > 0 && sc->root[0].kind == RTAMD_ROOT_OBJECT) {
+        bool range = true;
+        for (uint32_t k = 0; k < sc->n_root && range; k++)
+            range = sc->root[k].kind == RTAMD_ROOT_OBJECT && sc->root[k].index == sc->root[0].index + k;
+        if (range) S.root_first = sc->root[0].index;
+    }
     {
         size_t tb = (size_t)sc->n_objects * sizeof(DevObject) + (size_t)sc->n_ops * 48 + (size_t)sc->n_cuboids * 48 + (((size_t)sc->n_root * 8 + 15) & ~(size_t)15);
         S.tab_bytes = tb <= 8192 ? (uint32_t)tb : 0u;

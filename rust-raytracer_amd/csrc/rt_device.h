@@ -70,6 +70,7 @@ struct DevScene {
     const uint32_t* sky;  // RGBA8, one word per texel
     uint32_t n_root, n_lights, sky_w, sky_h;
     uint32_t n_objects, n_meshes;
+    uint32_t root_first;      // root list = plain objects root_first, root_first + 1, ...: that first index; else MISS
     uint32_t lds_mesh;        // mesh index staged in LDS by the trace kernels, or MISS
     uint32_t lds_bytes;       // bytes of LDS needed for that mesh
     uint32_t n_ops, n_cuboids;
@@ -364,10 +365,13 @@ __device__ __forceinline__ void ops_hit_out(const Tab& tab, uint32_t first, uint
 
 // The same wrappers applied from an object record's inline parameters (xf_kind without XF_GENERIC):
 // identical operations in identical order, without the walk over the op list.
-__device__ __forceinline__ void xf_in(uint32_t xf_kind, const ObjXf& x, float inv_scale, f3& pos, f3& dir, float& t_max) {
+__device__ __forceinline__ void xf_in_pos(uint32_t xf_kind, const ObjXf& x, float inv_scale, f3& pos, float& t_max) {
     if (xf_kind & XF_T) pos = pos - x.off;
     if (xf_kind & XF_S) { pos = pos * inv_scale; t_max = t_max * inv_scale; }
-    if (xf_kind & XF_R) { pos = mat_transpose_apply(x.rot, pos); dir = mat_transpose_apply(x.rot, dir); }
+    if (xf_kind & XF_R) pos = mat_transpose_apply(x.rot, pos);
+}
+__device__ __forceinline__ f3 xf_in_dir(uint32_t xf_kind, const ObjXf& x, f3 dir) {
+    return (xf_kind & XF_R) ? mat_transpose_apply(x.rot, dir) : dir;
 }
 
 // ------------------------------------------------------------------------------------------------

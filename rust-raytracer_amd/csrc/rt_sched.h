@@ -45,13 +45,14 @@ static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
 // accumulated per wave and added to a global table when the wave ends.  Never compiled into librtamd.so.
 #ifdef RTAMD_DIAG
 __device__ unsigned long long g_diag[32];
-#define DIAG_DECL unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_steps[6] = {0, 0, 0, 0, 0, 0}, d_lanes[6] = {0, 0, 0, 0, 0, 0}; unsigned long long d_t0 = 0; unsigned long long d_sub[4] = {0, 0, 0, 0}, d_subn[4] = {0, 0, 0, 0};
+#define DIAG_DECL unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_steps[6] = {0, 0, 0, 0, 0, 0}, d_lanes[6] = {0, 0, 0, 0, 0, 0}; unsigned long long d_t0 = 0; unsigned long long d_sub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d_subn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define DIAG_TOP d_t0 = __builtin_amdgcn_s_memtime();
 #define DIAG_STEP(ph, c) { d_steps[ph] += 1; d_lanes[ph] += (c); }
 #define DIAG_END(ph) { d_cyc[ph] += __builtin_amdgcn_s_memtime() - d_t0; }
 #define DIAG_SUB_BEGIN unsigned long long d_s0 = __builtin_amdgcn_s_memtime();
 #define DIAG_SUB_END(slot) { d_sub[slot] += __builtin_amdgcn_s_memtime() - d_s0; d_subn[slot] += 1; }
-#define DIAG_FLUSH if (lane == 0) { for (int q = 0; q < 4; q++) { atomicAdd(&g_diag[15 + 2 * q], d_sub[q]); atomicAdd(&g_diag[16 + 2 * q], d_subn[q]); } } if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
+#define DIAG_SUB_MARK d_s0 = __builtin_amdgcn_s_memtime();
+#define DIAG_FLUSH if (lane == 0) { for (int q = 0; q < 8; q++) { atomicAdd(&g_diag[15 + 2 * q], d_sub[q]); atomicAdd(&g_diag[16 + 2 * q], d_subn[q]); } } if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
 #else
 #define DIAG_DECL
 #define DIAG_TOP
@@ -59,6 +60,7 @@ __device__ unsigned long long g_diag[32];
 #define DIAG_END(ph)
 #define DIAG_SUB_BEGIN
 #define DIAG_SUB_END(slot)
+#define DIAG_SUB_MARK
 #define DIAG_FLUSH
 #endif
 
@@ -157,7 +159,6 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                                                 lds_u32* coop /* this wave's COOP_WORDS */) {
     const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = (chunk_and_share >> 16) & 0xFu;
     const uint32_t lane = lane_id();
-    const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
     uint32_t st = ST_FETCH, fl = 0;
     uint32_t ridx = 0, rtag = 0;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     uint32_t root_i = 0;
     uint32_t t_i = 0, t_n = 0, t_base = 0, t_first = 0;
     uint32_t o_cur = 0, o_end = 0;
-    uint32_t oi = 0, op_first = 0, op_count = 0;
+    uint32_t oi = 0;
     f3 opos = mk(0, 0, 0), odir = mk(0, 0, 1), oinv = mk(0, 0, 0);
     float otmax = 0.0f, oscale = 1.0f;
     uint32_t n_i = 0, n_n = 0, node_off = 0, tri_off = 0;
@@ -347,11 +348,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           // whose root box the ray misses (most instances, for most rays): its root is tested right here.
           for (uint32_t c = c_obj; c * STAY_DEN >= c_obj * STAY_NUM && c > 0; c = wave_count(st == ST_OBJ)) {
             DIAG_STEP(ST_OBJ, c)
+            DIAG_SUB_BEGIN
             if (st == ST_OBJ) {
                 // (1) fold a finished mesh walk into the ray's closest hit (bvh.rs:262-264, transform.rs:107)
                 if ((fl & (F_PEND | F_FOUND)) == (F_PEND | F_FOUND)) {
                     best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
-                    wtmax = (fl & F_GENXF) ? ops_t_out(tab, op_first, op_count, otmax) : otmax * oscale;
+                    wtmax = otmax * oscale;
+                    if (fl & F_GENXF) { const ObjHead ob = tab.object(oi); wtmax = ops_t_out(tab, ob.op_first, ob.op_count, otmax); }
                 }
                 fl &= ~(F_PEND | F_FOUND);
                 // (2) where does the next object come from?
@@ -375,25 +378,32 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         }
                     }
                 }
+                DIAG_SUB_END(3)
+                DIAG_SUB_MARK
                 // (3) enter the next object
                 if (st == ST_OBJ && o_cur < o_end) {
                     oi = o_cur++;
                     const ObjHead ob = tab.object(oi);
-                    op_first = ob.op_first; op_count = ob.op_count;
-                    opos = wpos; odir = wdir; otmax = wtmax;
+                    const ObjXf xf = tab.object_xf(oi);   // read with the head: one LDS round trip instead of two
+                    opos = wpos; otmax = wtmax;
+                    odir = wdir;
                     oscale = ob.scale;
                     if (ob.xf_kind & XF_GENERIC) {
                         fl |= F_GENXF;
-                        ops_in(tab, op_first, op_count, opos, odir, otmax);
+                        ops_in(tab, ob.op_first, ob.op_count, opos, odir, otmax);
                     } else {
                         fl &= ~F_GENXF;
-                        if (ob.xf_kind) xf_in(ob.xf_kind, tab.object_xf(oi), ob.inv_scale, opos, odir, otmax);
+                        xf_in_pos(ob.xf_kind, xf, ob.inv_scale, opos, otmax);
+                        odir = xf_in_dir(ob.xf_kind, xf, wdir);
                     }
+                    DIAG_SUB_END(4)
+                    DIAG_SUB_MARK
                     if (ob.geom_kind == GEOM_MESH) {
                         n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
                         if (MESHLOC == MESH_MIXED) fl = (ob.geom_index == S.lds_mesh) ? (fl | F_MLDS) : (fl & ~F_MLDS);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
                         if (n_n > 0) node_step();
+                        DIAG_SUB_END(5)
                     } else {
                         float t = 0.0f;
                         bool hit;
@@ -405,7 +415,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                             hit = primitive_closest(S, tab, ob, opos, odir, otmax, t, u, v);
                             if (hit) {
                                 best.obj = oi; best.prim = 0; best.t_local = t; best.u = u; best.v = v;
-                                wtmax = (fl & F_GENXF) ? ops_t_out(tab, op_first, op_count, t) : t * oscale;
+                                wtmax = (fl & F_GENXF) ? ops_t_out(tab, ob.op_first, ob.op_count, t) : t * ob.scale;
                             }
                         }
                     }
@@ -417,7 +427,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             const bool want = st == ST_FETCH;
             // hand out staged rays to the lanes that want one
             const unsigned long long need = __ballot(want);
-            const uint32_t rank = (uint32_t)__builtin_popcountll(need & lt_mask);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));  // wanting lanes below this one
             const uint32_t avail = sg_cnt - sg_pos;
             const uint32_t take = c_fetch < avail ? c_fetch : avail;
             const bool got = want && rank < take;
@@ -442,7 +452,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 ridx = sg_base + sg_pos + rank;
                 io.decode(ridx, raw, wpos, wdir, wtmax, any, rtag);
                 best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
-                root_i = 0; o_cur = 0; o_end = 0;
+                // a root list that is one run of objects is walked as a range (no list reads)
+                const bool run = S.root_first != MISS;
+                root_i = run ? S.n_root : 0u; o_cur = run ? S.root_first : 0u; o_end = run ? S.root_first + S.n_root : 0u;
                 fl = any ? F_ANY : 0u;
                 st = ST_OBJ;
             }
