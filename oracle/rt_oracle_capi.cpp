@@ -235,6 +235,10 @@ void* orc_scene_terrain(const char* ply_path, int n, uint64_t seed, int with_bun
     s->scene.root = list;
     s->scene.skybox = make_sky(sky_rgb, sky_w, sky_h);
     s->scene.lights = main_lights();
+    // two point lights (light.rs:34-79): a ball of radius 0.5 and a true point
+    Light p1; p1.kind = LIGHT_POINT; p1.vec = V3(2.0f, -3.0f, 4.0f); p1.param = std::fabs(0.5f); p1.emission = V3(1.0f, 0.9f, 0.8f) * 12.0f;
+    Light p2; p2.kind = LIGHT_POINT; p2.vec = V3(-4.0f, 3.0f, 2.5f); p2.param = std::fabs(0.0f); p2.emission = V3(0.6f, 0.7f, 1.0f) * 6.0f;
+    s->scene.lights.push_back(p1); s->scene.lights.push_back(p2);
     return s;
 }
 

@@ -454,7 +454,6 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     ctx->lights.clear();
     for (uint32_t k = 0; k < sc->n_lights; k++) {
         const rtamd_light& l = sc->lights[k];
-        if (l.kind == RTAMD_LIGHT_POINT) return fail(ctx, RTAMD_E_UNSUPPORTED, "point lights are not supported on the device yet");
         if (l.kind > RTAMD_LIGHT_AO) return fail(ctx, RTAMD_E_INVALID, "unknown light kind");
         DevLight d{};
         d.kind = l.kind; std::memcpy(d.vec, l.vec, 12); d.param = l.param; std::memcpy(d.emission, l.emission, 12);

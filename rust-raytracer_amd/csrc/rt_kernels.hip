@@ -301,10 +301,34 @@ __device__ __forceinline__ bool light_is_delta(const DevLight& l) {  // light.rs
     if (l.kind == LIGHT_DIRECTION) return l.param > 0.0f;
     return false;
 }
-__device__ __forceinline__ void light_sample(const DevLight& l, f3 normal, Rng& rng, f3& dir, float& t_max, f3& ill) {
+__device__ __forceinline__ void light_sample(const DevLight& l, f3 pos, f3 normal, Rng& rng, f3& dir, float& t_max, f3& ill) {
     f3 E = mk(l.emission[0], l.emission[1], l.emission[2]);
     if (l.kind == LIGHT_AMBIENT) {  // light.rs:24-27
         dir = normal; t_max = 0.0f; ill = E;
+    } else if (l.kind == LIGHT_POINT) {  // light.rs:50-74
+        // rejection-sample a point of the unit ball; gen_range(-1, 1) draws a float in [1, 2) from the top 23 bits of a
+        // u32, maps it with value * scale + (low - scale), and redraws a result that rounds up to the high end
+        f3 fv;
+        for (;;) {
+            float f[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                for (;;) {
+                    const float v12 = __uint_as_float((rng_u32(rng) >> 9) | 0x3F800000u);
+                    const float scale = 1.0f - (-1.0f);
+                    const float res = v12 * scale + (-1.0f - scale);
+                    if (res < 1.0f) { f[k] = res; break; }
+                }
+            }
+            fv = mk(f[0], f[1], f[2]);
+            if (dot(fv, fv) < 1.0f) break;
+        }
+        const f3 offset = (mk(l.vec[0], l.vec[1], l.vec[2]) + fv * l.param) - pos;
+        const float dist_sq = dot(offset, offset);
+        const float dist = sqrtf(dist_sq);
+        dir = offset / dist;
+        const float c = rust_max(dot(dir, normal), 0.0f);
+        t_max = dist; ill = (E / dist_sq) * c;
     } else if (l.kind == LIGHT_DIRECTION) {  // light.rs:97-123
         f3 ld = mk(l.vec[0], l.vec[1], l.vec[2]);
         f3 o;
@@ -572,7 +596,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
                     f3 sd = mk(0, 0, 0), ill = mk(0, 0, 0);
                     float tm = 0.0f;
                     if (lit) {
-                        light_sample(lt, nrm, rng, sd, tm, ill);
+                        light_sample(lt, p, nrm, rng, sd, tm, ill);
                         float* q = W.smp + (size_t)s * 4 * cap + lq;
                         q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z;
                         shoot = !(tm == 0.0f);                         // integrator.rs:124

@@ -144,6 +144,9 @@ Scene scene_terrain(const std::string& ply_path, int n, uint64_t seed, bool with
     scene.camera = cam;
     scene.skybox = skybox;
     scene.lights = main_lights();
+    // two point lights (light.rs:34-79): a ball of radius 0.5 and a true point
+    scene.lights.push_back(PointLight(Vec3D(2.0f, -3.0f, 4.0f), 0.5f, Vec3D(1.0f, 0.9f, 0.8f), 12.0f));
+    scene.lights.push_back(PointLight(Vec3D(-4.0f, 3.0f, 2.5f), 0.0f, Vec3D(0.6f, 0.7f, 1.0f), 6.0f));
     return scene;
 }
 

@@ -90,6 +90,17 @@ def test_sphere_and_grid_scenes_render(rt, ol, sky):
         compare(img, ref)
 
 
+def test_terrain_scene_with_point_lights_renders(rt, ol, sky):
+    """Two meshes (one in LDS, one in global memory) and the PointLight sampler (ball and true point)."""
+    cam = (200, 150)
+    gpu, cpu = rt.Scene.terrain(40, seed=2, sky=sky, cam=cam).upload(0), ol.OracleScene.terrain(40, seed=2, sky=sky, cam=cam)
+    for params in (dict(max_depth=4, shadow_rays=1, antialiasing=2), dict(max_depth=2, shadow_rays=3, antialiasing=1)):
+        img, st = gpu.render(**params)
+        ref, _, cnt = cpu.render(**params)
+        compare(img, ref)
+        assert abs(st["any_rays"] - cnt["any_rays"]) <= 2e-3 * max(1, cnt["any_rays"])
+
+
 def test_quantizer_matches(rt, ol, pair):
     import torch
     gpu, _, _ = pair

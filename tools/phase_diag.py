@@ -23,10 +23,14 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--cam", default="1080x960")
     ap.add_argument("--opt", default="")
+    ap.add_argument("--scene", default="bunny", choices=["bunny", "spheres", "grid", "terrain"])
     args = ap.parse_args()
     rt = entry.load_package()
     w, h = map(int, args.cam.split("x"))
-    scene = rt.Scene.main(sky=rt.load_skybox(max_width=2048), cam=(w, h)).upload(0)
+    sky = rt.load_skybox(max_width=2048)
+    make = {"bunny": lambda: rt.Scene.main(sky=sky, cam=(w, h)), "spheres": lambda: rt.Scene.spheres(n=10000, seed=1, sky=sky, cam=(w, h)),
+            "grid": lambda: rt.Scene.grid(230, 230, sky=sky, cam=(w, h)), "terrain": lambda: rt.Scene.terrain(300, seed=1, with_bunny=True, sky=sky, cam=(w, h))}
+    scene = make[args.scene]().upload(0)
     opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH}
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
@@ -43,7 +47,7 @@ def main():
         rays = st["closest_rays"] + st["any_rays"]
         total = d[:, 0].sum()
         print(f"max_depth {depth}: rays {rays} ({st['closest_rays']} closest, {st['any_rays']} any), device {st['device_ms']:.2f} ms")
-        for name, (cyc, steps, lanes) in zip(("FETCH", "OBJ", "TNODE", "NODE", "TRI"), d):
+        for name, (cyc, steps, lanes) in zip(("FETCH", "OBJ", "TNODE", "NODE", "TRI"), d):  # noqa: E501
             if steps:
                 print(f"  {name:6s} cycles {100 * cyc / total:5.1f}%  steps {int(steps):>12d}  lanes/step {lanes / steps:5.1f}  "
                       f"cycles/step {cyc / steps:7.1f}  lane-steps/ray {lanes / rays:6.2f}")

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Whole-frame Mrays/s of the synthetic scenes next to the bunny scene (one GPU).
+
+    python tools/scene_rates.py [--spp-root 4]
+
+Scenes: bunny (reference main.rs), 10 000 spheres in an object tree, 230 x 230 instanced bunnies in an object tree
+(50.1 M triangles), a 300 x 300 heightfield with two bunnies (mesh trees in global memory and LDS mixed).
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--spp-root", type=int, default=4)
+    ap.add_argument("--cam", default="1080x960")
+    args = ap.parse_args()
+    rt = entry.load_package()
+    w, h = map(int, args.cam.split("x"))
+    sky = rt.load_skybox(max_width=2048)
+    scenes = [
+        ("bunny", lambda: rt.Scene.main(sky=sky, cam=(w, h))),
+        ("spheres_10k", lambda: rt.Scene.spheres(n=10000, seed=1, sky=sky, cam=(w, h))),
+        ("bunny_grid_230x230", lambda: rt.Scene.grid(230, 230, sky=sky, cam=(w, h))),
+        ("terrain_300_two_bunnies", lambda: rt.Scene.terrain(300, seed=1, with_bunny=True, sky=sky, cam=(w, h))),
+    ]
+    for name, make in scenes:
+        t0 = time.perf_counter()
+        s = make()
+        t_build = time.perf_counter() - t0
+        s.upload(0)
+        s.render(max_depth=5, shadow_rays=1, antialiasing=1)
+        _, st = s.render(max_depth=5, shadow_rays=1, antialiasing=args.spp_root)
+        rays = st["closest_rays"] + st["any_rays"]
+        print(f"{name:26s} host build {t_build:6.2f} s  rays {rays:>11d}  device {st['device_ms']:8.2f} ms  {rays / st['device_ms'] / 1e3:8.1f} Mrays/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
