@@ -290,7 +290,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     float4 q0, q1, q2;
                     if (p_lds) {
                         lds_float4* tp = lds.tris + 3 * k;
-                        q0 = lds_load4(tp); q1 = lds_load4(tp + 1); q2 = lds_load4(tp + 2);
+                        q0 = lds_load4(tp); q1 = lds_load4(tp + 1);
+                        // only ac.z of the third quad is needed (the rest are vertex ids for the shade stage)
+                        q2 = make_float4(((__attribute__((address_space(3))) const float*)tp)[8], 0.f, 0.f, 0.f);
                     } else {
                         const float4* tp = S.tris + 3 * ((size_t)p_tri_off + k);
                         q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
