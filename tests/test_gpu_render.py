@@ -101,6 +101,20 @@ def test_terrain_scene_with_point_lights_renders(rt, ol, sky):
         assert abs(st["any_rays"] - cnt["any_rays"]) <= 2e-3 * max(1, cnt["any_rays"])
 
 
+def test_tuning_options_do_not_change_pixels(rt, sky):
+    """Work distribution knobs (streams, static share, batch size, chunk, blocks, LDS staging) leave every pixel bit-identical."""
+    gpu = rt.Scene.main(sky=sky, cam=(320, 256)).upload(0)
+    params = dict(max_depth=4, shadow_rays=2, antialiasing=2)
+    ref, st0 = gpu.render(**params)
+    for opt, val, back in ((rt.OPT_STREAMS, 3, 1), (rt.OPT_STATIC_SHARE, 0, 6), (rt.OPT_STATIC_SHARE, 8, 6), (rt.OPT_MIN_BATCH, 64, 4),
+                           (rt.OPT_CHUNK, 256, 64), (rt.OPT_BLOCKS_PER_CU, 1, 2), (rt.OPT_MAX_PATHS, 20000, 1 << 22), (rt.OPT_LDS_SCENE, 0, 1)):
+        gpu.set_option(opt, val)
+        img, st = gpu.render(**params)
+        gpu.set_option(opt, back)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (opt, val)
+        assert (st["closest_rays"], st["any_rays"]) == (st0["closest_rays"], st0["any_rays"])
+
+
 def test_quantizer_matches(rt, ol, pair):
     import torch
     gpu, _, _ = pair
