@@ -151,7 +151,9 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
     if ((rc = wave_alloc(ctx, ws, &W.rng_lo, cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.rng_hi, cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.sum, 3 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.L, 3 * cap))) return rc;
+    for (int k = 0; k < 2; k++)
+        if ((rc = wave_alloc(ctx, ws, &W.Lb[k], 3 * cap))) return rc;
+    W.L = W.Lb[0];
     if ((rc = wave_alloc(ctx, ws, &W.beta, 3 * cap))) return rc;
     for (int k = 0; k < 2; k++) {
         if ((rc = wave_alloc(ctx, ws, &W.q_slot[k], cap))) return rc;
@@ -164,7 +166,7 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
     if ((rc = wave_alloc(ctx, ws, &W.a_ray, 7 * S * cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.a_vidx, S * cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.vis, S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.counts, (size_t)CounterSlots::TOTAL))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.counts, (size_t)2 * CounterSlots::TOTAL))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.stats, (size_t)16))) return rc;
     ws.cap = cap; ws.samples = samples;
     return RTAMD_OK;
@@ -655,44 +657,59 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                 const size_t begin = g * cap;
                 const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
                 const size_t any_upper = (size_t)chunk_n * (S_total ? S_total : 1);
-                if (pass == aa * aa) {
-                    HIP_TRY(ctx, launch_finalize(W, R, (uint32_t)begin, chunk_n, (float)(aa * aa), out, st));
+                const uint32_t n_pass = aa * aa;
+                // Sample pass k works in counter set k & 1 and radiance buffer k & 1.  The shadow rays of its last bounce
+                // are not traced by a launch of their own: they ride with the primary rays of pass k + 1 (or, after the
+                // last pass, with nothing), and are resolved into buffer k & 1 while pass k + 1 fills the other one.
+                const uint32_t cb = (pass & 1u) * CS::TOTAL, pb = ((pass + 1u) & 1u) * CS::TOTAL;   // this pass / previous pass
+                WaveBufs Wp = W;                        // the previous pass's view: its radiance buffer
+                W.L = W.Lb[pass & 1u];
+                Wp.L = W.Lb[(pass + 1u) & 1u];
+                if (pass == n_pass) {
+                    if (D > 0 && n_pass > 0) {  // shadow rays of the last bounce of the last pass
+                        timed_begin(ctx, 1, st);
+                        HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, Wp, (uint32_t)(D & 1), MISS, pb + CS::ANY + (D - 1), pb + CS::HEAD + D, any_upper, st));
+                        timed_end(ctx, st);
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, integ->shadow_rays, pb + CS::LIT + (D - 1), chunk_n, st));
+                        launches += 2;
+                    }
+                    // unfolded so far: pass n_pass - 2 (in the buffer this index would use) and pass n_pass - 1
+                    HIP_TRY(ctx, launch_finalize(W, R, (uint32_t)begin, chunk_n, (float)n_pass, n_pass >= 2 ? W.L : nullptr, Wp.L, out, st));
                     launches++;
                     continue;
                 }
                 const uint32_t si = pass / aa, sj = pass % aa;
-                HIP_TRY(ctx, hipMemsetAsync(W.counts, 0, CS::TOTAL * 4, st));
-                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, pass == 0, CS::Q + 0, st));
+                HIP_TRY(ctx, hipMemsetAsync(W.counts + cb, 0, CS::TOTAL * 4, st));
+                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, pass == 0 ? 0u : (pass == 1 ? 1u : 2u), cb + CS::Q + 0, st));
                 launches++;
                 uint32_t cur = 0;
                 if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
-                    HIP_TRY(ctx, launch_mark_miss(W, CS::Q + 0, chunk_n, st));
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, 0, 1, integ->shadow_rays, CS::Q + 0, CS::Q + 1, CS::LIT + 0, CS::ANY + 0, chunk_n, st));
+                    HIP_TRY(ctx, launch_mark_miss(W, cb + CS::Q + 0, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, 0, 1, integ->shadow_rays, cb + CS::Q + 0, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, chunk_n, st));
                     launches += 2;
                 }
                 for (int d = 0; d < D; d++) {
-                    // trace: closest-hit rays of bounce d together with the shadow rays of bounce d-1
+                    // trace: closest-hit rays of bounce d together with the shadow rays of the bounce before
+                    // (for d = 0: of the last bounce of the previous pass)
+                    const bool carry = d == 0 && pass > 0;
+                    const uint32_t a_idx = d > 0 ? cb + CS::ANY + (d - 1) : (carry ? pb + CS::ANY + (D - 1) : MISS);
                     timed_begin(ctx, 0, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, CS::Q + d, d > 0 ? CS::ANY + (d - 1) : MISS, CS::HEAD + d,
-                                                   chunk_n + (d > 0 ? any_upper : 0), st));
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, cb + CS::Q + d, a_idx, cb + CS::HEAD + d,
+                                                   chunk_n + (a_idx != MISS ? any_upper : 0), st));
                     timed_end(ctx, st);
                     launches++;
                     timed_begin(ctx, 2, st);
                     if (d > 0) {
-                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, integ->shadow_rays, CS::LIT + (d - 1), chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, integ->shadow_rays, cb + CS::LIT + (d - 1), chunk_n, st));
+                        launches++;
+                    } else if (carry) {
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, integ->shadow_rays, pb + CS::LIT + (D - 1), chunk_n, st));
                         launches++;
                     }
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, d, D, integ->shadow_rays, CS::Q + d, CS::Q + d + 1, CS::LIT + d, CS::ANY + d, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, d, D, integ->shadow_rays, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, chunk_n, st));
                     timed_end(ctx, st);
                     launches++;
                     cur ^= 1;
-                }
-                if (D > 0) {  // shadow rays of the last bounce
-                    timed_begin(ctx, 1, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, MISS, CS::ANY + (D - 1), CS::HEAD + D, any_upper, st));
-                    timed_end(ctx, st);
-                    HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, integ->shadow_rays, CS::LIT + (D - 1), chunk_n, st));
-                    launches += 2;
                 }
             }
         }

@@ -33,7 +33,9 @@ struct WaveBufs {
     uint64_t* rng_lo;     // SmallRng state, low / high half
     uint64_t* rng_hi;
     float* sum;           // 3*cap: sum of finished samples
-    float* L;             // 3*cap: radiance of the sample in flight
+    float* L;             // 3*cap: radiance of the sample the launch works on (one of Lb, set by the host per launch)
+    float* Lb[2];         // the two radiance buffers: sample pass k accumulates into Lb[k & 1] while the last shadow rays
+                          // of pass k-1 are still being resolved into the other one
     float* beta;          // 3*cap: path throughput
     // closest-hit ray queues, double buffered by bounce parity
     uint32_t* q_slot[2];  // cap: pixel slot of the path
@@ -51,7 +53,8 @@ struct WaveBufs {
     float* a_ray;         // 7*any_cap: pos.xyz, dir.xyz, t_max
     uint32_t* a_vidx;     // any_cap: index into vis (sample * cap + lit index)
     uint8_t* vis;         // S*cap: 1 = occluded
-    // counters, zeroed once per sample pass: see CounterSlots
+    // counters: two sets of CounterSlots::TOTAL (sample pass k uses set k & 1, zeroed when the pass starts); kernels
+    // take absolute indices into this array
     uint32_t* counts;
     uint64_t* stats;      // [0] closest-hit rays, [1] any-hit rays
 };
@@ -78,15 +81,19 @@ struct LaunchCfg {
 
 hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st);
 hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, uint8_t* out, size_t n, uint32_t* work_head, hipStream_t st);
+// fold: 0 = first sample of the pixel (seed the stream, zero the sum), 1 = leave the sum alone, 2 = add the old content
+// of W.L (the sample two passes back) to the sum; W.L is zeroed in every case.
 hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
-                         uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t q_idx, hipStream_t st);
+                         uint32_t si, uint32_t sj, uint32_t aa, uint32_t fold, uint32_t q_idx, hipStream_t st);
 hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st);
 hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
                              uint32_t head_idx, size_t upper, hipStream_t st);
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
                              int shadow_rays, uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st);
 hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, size_t upper, hipStream_t st);
-hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out, hipStream_t st);
+// pixel = (sum + L_first + L_second) / n_samples; L_first may be null (a single sample pass)
+hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L_first,
+                           const float* L_second, float* out, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 #ifdef RTAMD_DIAG
 hipError_t diag_read(unsigned long long* out, int reset);

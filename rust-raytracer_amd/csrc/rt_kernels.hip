@@ -411,7 +411,7 @@ __device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, ui
 // pixel sum (integrator.rs:50-53 adds the samples in generation order).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R, CameraDev cam, uint32_t chunk_begin, uint32_t chunk_n,
-                                                uint32_t si, uint32_t sj, uint32_t aa, uint32_t first_sample, uint32_t q_idx) {
+                                                uint32_t si, uint32_t sj, uint32_t aa, uint32_t fold, uint32_t q_idx) {
     __shared__ uint32_t sh_app[STAGE_BLOCK / 64];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
@@ -419,12 +419,12 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R,
     if (i < chunk_n) valid = slot_pixel(R, chunk_begin + i, cx, cy);
     f3 pos = mk(0, 0, 0), dir = mk(0, 0, 0);
     if (valid) {
-        if (first_sample) {
+        if (fold == 0u) {
             uint64_t seed = (uint64_t)cx ^ __builtin_bswap64((uint64_t)cy);  // integrator.rs:36
             Rng r = rng_seed(seed);
             W.rng_lo[i] = r.lo; W.rng_hi[i] = r.hi;
             W.sum[i] = 0.0f; W.sum[i + W.cap] = 0.0f; W.sum[i + 2 * W.cap] = 0.0f;
-        } else {
+        } else if (fold == 2u) {
             W.sum[i] = W.sum[i] + W.L[i];
             W.sum[i + W.cap] = W.sum[i + W.cap] + W.L[i + W.cap];
             W.sum[i + 2 * W.cap] = W.sum[i + 2 * W.cap] + W.L[i + 2 * W.cap];
@@ -682,16 +682,22 @@ __global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, in
 // ------------------------------------------------------------------------------------------------
 // Stage 5: pixel = mean of the samples (integrator.rs:50-53), written to the tile-major output.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(WaveBufs W, RegionDev R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out) {
+__global__ __launch_bounds__(256) void k_finalize(WaveBufs W, RegionDev R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L1,
+                                                  const float* L2, float* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= chunk_n) return;
     uint32_t cx, cy;
     bool valid = slot_pixel(R, chunk_begin + i, cx, cy);
     size_t o = 3 * (size_t)(chunk_begin + i);
     if (valid) {
-        out[o] = (W.sum[i] + W.L[i]) / n_samples;
-        out[o + 1] = (W.sum[i + W.cap] + W.L[i + W.cap]) / n_samples;
-        out[o + 2] = (W.sum[i + 2 * W.cap] + W.L[i + 2 * W.cap]) / n_samples;
+        // the samples are added in generation order (integrator.rs:50-53): the sum, then the last two passes
+#pragma unroll
+        for (uint32_t c = 0; c < 3; c++) {
+            float v = W.sum[i + c * W.cap];
+            if (L1 != nullptr) v = v + L1[i + c * W.cap];
+            v = v + L2[i + c * W.cap];
+            out[o + c] = v / n_samples;
+        }
     } else {
         out[o] = 0.0f; out[o + 1] = 0.0f; out[o + 2] = 0.0f;
     }
@@ -783,9 +789,9 @@ hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBa
     return hipGetLastError();
 }
 hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
-                         uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t q_idx, hipStream_t st) {
+                         uint32_t si, uint32_t sj, uint32_t aa, uint32_t fold, uint32_t q_idx, hipStream_t st) {
     uint32_t g = (chunk_n + STAGE_BLOCK - 1) / STAGE_BLOCK;
-    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(STAGE_BLOCK), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, first ? 1u : 0u, q_idx);
+    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(STAGE_BLOCK), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, fold, q_idx);
     return hipGetLastError();
 }
 hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st) {
@@ -818,9 +824,10 @@ hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const Wa
     hipLaunchKernelGGL(k_wave_resolve, dim3(g), dim3(256), 0, st, S, W, shadow_rays, lit_idx);
     return hipGetLastError();
 }
-hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, float* out, hipStream_t st) {
+hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L_first,
+                           const float* L_second, float* out, hipStream_t st) {
     uint32_t g = (chunk_n + 255) / 256;
-    hipLaunchKernelGGL(k_finalize, dim3(g), dim3(256), 0, st, W, R, chunk_begin, chunk_n, n_samples, out);
+    hipLaunchKernelGGL(k_finalize, dim3(g), dim3(256), 0, st, W, R, chunk_begin, chunk_n, n_samples, L_first, L_second, out);
     return hipGetLastError();
 }
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st) {
