@@ -50,6 +50,10 @@ static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
 #ifndef RTAMD_VOTE_W
 #define RTAMD_VOTE_W 16, 16, 1, 1, 1
 #endif
+#ifndef RTAMD_VOTE_MESH_MIN
+#define RTAMD_VOTE_MESH_MIN 16
+#endif
+static constexpr uint32_t VOTE_MESH_MIN = RTAMD_VOTE_MESH_MIN;
 static constexpr uint32_t VOTE_W[5] = {RTAMD_VOTE_W};
 static constexpr uint32_t VOTE_W_TRI = VOTE_W[0], VOTE_W_NODE = VOTE_W[1], VOTE_W_OBJ = VOTE_W[2], VOTE_W_FETCH = VOTE_W[3], VOTE_W_TNODE = VOTE_W[4];
 
@@ -244,8 +248,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t c_fetch = wave_count(st == ST_FETCH);
         if ((c_tri | c_node | c_tnode | c_obj | c_fetch) == 0) break;  // every lane is ST_DONE
         // most lanes wins; ties go to the deeper phase (the state codes grow with depth)
-        uint32_t key = ((c_tri * VOTE_W_TRI) << 3) | ST_TRI;
-        key = max(key, ((c_node * VOTE_W_NODE) << 3) | ST_NODE);
+        // the mesh phases get their weight only while enough lanes are in a mesh walk: with a few lanes there
+        // (rays scattered over the instances of a large scene) running them first would serialise the wave
+        const bool mesh_first = c_tri + c_node >= VOTE_MESH_MIN;
+        uint32_t key = ((c_tri * (mesh_first ? VOTE_W_TRI : 1u)) << 3) | ST_TRI;
+        key = max(key, ((c_node * (mesh_first ? VOTE_W_NODE : 1u)) << 3) | ST_NODE);
         key = max(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
         key = max(key, ((c_obj * VOTE_W_OBJ) << 3) | ST_OBJ);
         key = max(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);

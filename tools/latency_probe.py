@@ -39,7 +39,7 @@ def main():
     occ = torch.zeros(n_all, dtype=torch.uint8, device=dev)
     scene.set_option(rt.OPT_PROFILE, 1)
     for kind in ("closest", "any"):
-        for n in (1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
+        for n in (1, 64, 1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
             if n > n_all:
                 break
             for rep in range(3):
