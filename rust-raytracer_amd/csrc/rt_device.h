@@ -301,6 +301,7 @@ __device__ __forceinline__ CuboidRec unpack_cuboid(float4 a, float4 b, float4 c)
     return r;
 }
 struct GlobalTab {
+    static constexpr bool small_scene = false;
     const DevScene* S;
     __device__ __forceinline__ ObjHead object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1], p[2]); }
     __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_xf(p[3], p[4], p[5]); }
@@ -309,6 +310,7 @@ struct GlobalTab {
     __device__ __forceinline__ DevRootItem root(uint32_t i) const { return S->root[i]; }
 };
 struct LdsTab {
+    static constexpr bool small_scene = true;   // the tables fit the LDS budget
     lds_float4* objects;  // 6 per object
     lds_float4* ops;      // 3 per op
     lds_float4* cuboids;  // 3 per cuboid

@@ -248,9 +248,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t c_fetch = wave_count(st == ST_FETCH);
         if ((c_tri | c_node | c_tnode | c_obj | c_fetch) == 0) break;  // every lane is ST_DONE
         // most lanes wins; ties go to the deeper phase (the state codes grow with depth)
-        // the mesh phases get their weight only while enough lanes are in a mesh walk: with a few lanes there
-        // (rays scattered over the instances of a large scene) running them first would serialise the wave
-        const bool mesh_first = c_tri + c_node >= VOTE_MESH_MIN;
+        // The mesh phases always get their weight in a small scene (its tables fit LDS): the rays walk few objects
+        // in much the same order, so the mesh walks of a wave coincide.  In a scene of thousands of instances the
+        // rays are scattered over them, and running a handful of mesh lanes first would serialise the wave: there
+        // the weight applies only while at least VOTE_MESH_MIN lanes are in a mesh walk.
+        const bool mesh_first = Tab::small_scene || c_tri + c_node >= VOTE_MESH_MIN;
         uint32_t key = ((c_tri * (mesh_first ? VOTE_W_TRI : 1u)) << 3) | ST_TRI;
         key = max(key, ((c_node * (mesh_first ? VOTE_W_NODE : 1u)) << 3) | ST_NODE);
         key = max(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
