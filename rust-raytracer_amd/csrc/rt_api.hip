@@ -160,13 +160,19 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
         if ((rc = wave_alloc(ctx, ws, &W.q_ray[k], 6 * cap))) return rc;
     }
     if ((rc = wave_alloc(ctx, ws, &W.h_rec, 2 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.lit_slot, cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.lit_f, 6 * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.smp, 4 * S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.a_ray, 7 * S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.a_vidx, S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.vis, S * cap))) return rc;
-    if ((rc = wave_alloc(ctx, ws, &W.counts, (size_t)2 * CounterSlots::TOTAL))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.p_slot, cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.p_ray, 6 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.p_rec, 2 * cap))) return rc;
+    for (int k = 0; k < 2; k++) {
+        ShadeSet& T = W.set[k];
+        if ((rc = wave_alloc(ctx, ws, &T.lit_slot, cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &T.lit_f, 6 * cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &T.smp, 4 * S * cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &T.a_ray, 7 * S * cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &T.a_vidx, S * cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &T.vis, S * cap))) return rc;
+    }
+    if ((rc = wave_alloc(ctx, ws, &W.counts, (size_t)3 * CounterSlots::TOTAL))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.stats, (size_t)16))) return rc;
     ws.cap = cap; ws.samples = samples;
     return RTAMD_OK;
@@ -658,19 +664,25 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                 const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
                 const size_t any_upper = (size_t)chunk_n * (S_total ? S_total : 1);
                 const uint32_t n_pass = aa * aa;
-                // Sample pass k works in counter set k & 1 and radiance buffer k & 1.  The shadow rays of its last bounce
-                // are not traced by a launch of their own: they ride with the primary rays of pass k + 1 (or, after the
-                // last pass, with nothing), and are resolved into buffer k & 1 while pass k + 1 fills the other one.
-                const uint32_t cb = (pass & 1u) * CS::TOTAL, pb = ((pass + 1u) & 1u) * CS::TOTAL;   // this pass / previous pass
+                const int sr = integ->shadow_rays;
+                // Sample pass k works in counter set k % 3 and radiance buffer k & 1.  Bounce 0 leaves its lit queue and
+                // shadow rays in shade set 1, the other bounces in set 0.  Two kinds of rays do not get a trace launch
+                // of their own: the shadow rays of a pass's last bounce ride with the first trace launch of the next
+                // pass (after the last pass: a launch of their own) and are resolved into buffer k & 1 while pass k + 1
+                // fills the other one; and, for max_depth >= 2, the primary rays of pass k + 1, which depend on nothing
+                // that pass k computes, ride with the last bounce of pass k.
+                const uint32_t cb = (pass % 3u) * CS::TOTAL, pb = ((pass + 2u) % 3u) * CS::TOTAL, nb = ((pass + 1u) % 3u) * CS::TOTAL;
                 WaveBufs Wp = W;                        // the previous pass's view: its radiance buffer
                 W.L = W.Lb[pass & 1u];
                 Wp.L = W.Lb[(pass + 1u) & 1u];
+                const uint32_t last_set = D - 1 > 0 ? 0u : 1u;   // shade set of a pass's last bounce
                 if (pass == n_pass) {
                     if (D > 0 && n_pass > 0) {  // shadow rays of the last bounce of the last pass
                         timed_begin(ctx, 1, st);
-                        HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, Wp, (uint32_t)(D & 1), MISS, pb + CS::ANY + (D - 1), pb + CS::HEAD + D, any_upper, st));
+                        HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, Wp, 0, MISS, MISS, last_set ? MISS : pb + CS::ANY + (D - 1),
+                                                       last_set ? pb + CS::ANY + (D - 1) : MISS, pb + CS::HEAD + D, any_upper, st));
                         timed_end(ctx, st);
-                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, integ->shadow_rays, pb + CS::LIT + (D - 1), chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, pb + CS::LIT + (D - 1), last_set, chunk_n, st));
                         launches += 2;
                     }
                     // unfolded so far: pass n_pass - 2 (in the buffer this index would use) and pass n_pass - 1
@@ -678,38 +690,60 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     launches++;
                     continue;
                 }
-                const uint32_t si = pass / aa, sj = pass % aa;
-                HIP_TRY(ctx, hipMemsetAsync(W.counts + cb, 0, CS::TOTAL * 4, st));
-                HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, si, sj, aa, pass == 0 ? 0u : (pass == 1 ? 1u : 2u), cb + CS::Q + 0, st));
-                launches++;
-                uint32_t cur = 0;
-                if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
-                    HIP_TRY(ctx, launch_mark_miss(W, cb + CS::Q + 0, chunk_n, st));
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, 0, 1, integ->shadow_rays, cb + CS::Q + 0, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, chunk_n, st));
-                    launches += 2;
-                }
-                for (int d = 0; d < D; d++) {
-                    // trace: closest-hit rays of bounce d together with the shadow rays of the bounce before
-                    // (for d = 0: of the last bounce of the previous pass)
-                    const bool carry = d == 0 && pass > 0;
-                    const uint32_t a_idx = d > 0 ? cb + CS::ANY + (d - 1) : (carry ? pb + CS::ANY + (D - 1) : MISS);
+                const uint32_t fold = pass >= 2 ? 2u : 1u;
+                if (pass == 0 || D < 2) {  // otherwise the pass before has generated and traced this pass's primary rays
+                    HIP_TRY(ctx, hipMemsetAsync(W.counts + cb, 0, CS::TOTAL * 4, st));
+                    HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, pass / aa, pass % aa, aa, pass == 0, cb + CS::PQ, st));
+                    launches++;
+                    if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
+                        HIP_TRY(ctx, launch_mark_miss(W, cb + CS::PQ, chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, 1, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, chunk_n, st));
+                        launches += 2;
+                        continue;
+                    }
+                    // primary rays; with max_depth = 1 also the shadow rays of the previous pass (its only bounce: set 1)
+                    const bool carry = D == 1 && pass > 0;
                     timed_begin(ctx, 0, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, cur, cb + CS::Q + d, a_idx, cb + CS::HEAD + d,
-                                                   chunk_n + (a_idx != MISS ? any_upper : 0), st));
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, 0, MISS, cb + CS::PQ, MISS, carry ? pb + CS::ANY + 0 : MISS, cb + CS::HEAD + 0,
+                                                   chunk_n + (carry ? any_upper : 0), st));
+                    timed_end(ctx, st);
+                    launches++;
+                    if (carry) {
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, pb + CS::LIT + 0, 1u, chunk_n, st));
+                        launches++;
+                    }
+                }
+                timed_begin(ctx, 2, st);
+                HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, D, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, chunk_n, st));
+                timed_end(ctx, st);
+                launches++;
+                for (int d = 1; d < D; d++) {
+                    const bool ahead = d == D - 1 && pass + 1 < n_pass;   // the next pass's primary rays ride with this launch
+                    if (ahead) {
+                        HIP_TRY(ctx, hipMemsetAsync(W.counts + nb, 0, CS::TOTAL * 4, st));
+                        HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, (pass + 1) / aa, (pass + 1) % aa, aa, false, nb + CS::PQ, st));
+                        launches++;
+                    }
+                    // closest-hit rays of bounce d with the shadow rays of the bounce before; bounce 1 also takes the shadow
+                    // rays that the previous pass's last bounce left in set 0
+                    const bool carry = d == 1 && pass > 0;
+                    const uint32_t a0 = d == 1 ? (carry ? pb + CS::ANY + (D - 1) : MISS) : cb + CS::ANY + (d - 1);
+                    const uint32_t a1 = d == 1 ? cb + CS::ANY + 0 : MISS;
+                    timed_begin(ctx, 0, st);
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, (uint32_t)(d & 1), cb + CS::Q + d, ahead ? nb + CS::PQ : MISS, a0, a1, cb + CS::HEAD + d,
+                                                   chunk_n + (ahead ? chunk_n : 0) + (a0 != MISS ? any_upper : 0) + (a1 != MISS ? any_upper : 0), st));
                     timed_end(ctx, st);
                     launches++;
                     timed_begin(ctx, 2, st);
-                    if (d > 0) {
-                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, integ->shadow_rays, cb + CS::LIT + (d - 1), chunk_n, st));
-                        launches++;
-                    } else if (carry) {
-                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, integ->shadow_rays, pb + CS::LIT + (D - 1), chunk_n, st));
+                    if (carry) {
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, pb + CS::LIT + (D - 1), 0u, chunk_n, st));
                         launches++;
                     }
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, cur, d, D, integ->shadow_rays, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, sr, cb + CS::LIT + (d - 1), d == 1 ? 1u : 0u, chunk_n, st));
+                    launches++;
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, chunk_n, st));
                     timed_end(ctx, st);
                     launches++;
-                    cur ^= 1;
                 }
             }
         }

@@ -23,6 +23,17 @@ struct RegionDev {
     uint32_t tiles_x, n_tiles;
 };
 
+struct ShadeSet {
+    // lit queue: paths whose hit has a non-black diffuse colour
+    uint32_t* lit_slot;   // cap
+    float* lit_f;         // 6*cap: beta.xyz, diffuse.xyz
+    float* smp;           // 4*S*cap: per light sample t_max, ill.xyz
+    // shadow-ray queue
+    float* a_ray;         // 7*any_cap: pos.xyz, dir.xyz, t_max
+    uint32_t* a_vidx;     // any_cap: index into vis (sample * cap + lit index)
+    uint8_t* vis;         // S*cap: 1 = occluded
+};
+
 // Wavefront state of one chunk of `cap` pixel slots, structure-of-arrays in HBM.
 // Vectors are stored component-major: component c of element i lives at [c * cap + i], so a wave
 // reads 64 consecutive floats per component.
@@ -37,24 +48,25 @@ struct WaveBufs {
     float* Lb[2];         // the two radiance buffers: sample pass k accumulates into Lb[k & 1] while the last shadow rays
                           // of pass k-1 are still being resolved into the other one
     float* beta;          // 3*cap: path throughput
-    // closest-hit ray queues, double buffered by bounce parity
+    // closest-hit ray queues of the bounces d >= 1, double buffered by bounce parity
     uint32_t* q_slot[2];  // cap: pixel slot of the path
     float* q_ray[2];      // 6*cap: pos.xyz, dir.xyz
-    // hit records of the current queue (what Geometry::hit found; the shade stage rebuilds pos / normal)
+    // primary rays (bounce 0) have a queue and hit records of their own: they depend on nothing but the pixel and
+    // the sample index, so the primary rays of pass k+1 are traced together with the last bounce of pass k
+    uint32_t* p_slot;     // cap
+    float* p_ray;         // 6*cap
+    uint4* p_rec;         // 2*cap
     // One 32-byte record per path: {object index or MISS, primitive, t in the object's space, u} {v, -, -, -}.
     // Rays of a wave finish in no particular order, so their results are scattered writes; as one
     // record they touch one cache line per ray instead of five.
     uint4* h_rec;         // 2*cap
-    // lit queue: paths whose hit has a non-black diffuse colour
-    uint32_t* lit_slot;   // cap
-    float* lit_f;         // 6*cap: beta.xyz, diffuse.xyz
-    float* smp;           // 4*S*cap: per light sample t_max, ill.xyz
-    // shadow-ray queue of the bounce
-    float* a_ray;         // 7*any_cap: pos.xyz, dir.xyz, t_max
-    uint32_t* a_vidx;     // any_cap: index into vis (sample * cap + lit index)
-    uint8_t* vis;         // S*cap: 1 = occluded
-    // counters: two sets of CounterSlots::TOTAL (sample pass k uses set k & 1, zeroed when the pass starts); kernels
-    // take absolute indices into this array
+    // What a shade launch leaves for the trace and resolve launches after it.  Two sets: bounce 0 writes set 1,
+    // the other bounces set 0, because the last bounce of pass k and bounce 0 of pass k+1 are shaded back to
+    // back and their shadow rays are traced by the same launch.
+    ShadeSet set[2];
+    // counters: three sets of CounterSlots::TOTAL (sample pass k uses set k % 3, zeroed before its primary rays are
+    // generated, i.e. during pass k-1, while the last counters of pass k-2 may still be in use); kernels take absolute
+    // indices into this array
     uint32_t* counts;
     uint64_t* stats;      // [0] closest-hit rays, [1] any-hit rays
 };
@@ -65,7 +77,8 @@ struct CounterSlots {
     static constexpr uint32_t LIT = Q + MAX_DEPTH + 1;  // LIT + d : lit hits of bounce d
     static constexpr uint32_t ANY = LIT + MAX_DEPTH;    // ANY + d : shadow rays of bounce d
     static constexpr uint32_t HEAD = ANY + MAX_DEPTH;   // HEAD + d: work-queue head of trace launch d
-    static constexpr uint32_t TOTAL = HEAD + MAX_DEPTH + 1;
+    static constexpr uint32_t PQ = HEAD + MAX_DEPTH + 1;  // primary rays of the pass
+    static constexpr uint32_t TOTAL = PQ + 1;
 };
 
 struct LaunchCfg {
@@ -81,16 +94,20 @@ struct LaunchCfg {
 
 hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st);
 hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, uint8_t* out, size_t n, uint32_t* work_head, hipStream_t st);
-// fold: 0 = first sample of the pixel (seed the stream, zero the sum), 1 = leave the sum alone, 2 = add the old content
-// of W.L (the sample two passes back) to the sum; W.L is zeroed in every case.
+// first: first sample of the pixel (seed its random stream, zero its sum)
 hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
-                         uint32_t si, uint32_t sj, uint32_t aa, uint32_t fold, uint32_t q_idx, hipStream_t st);
+                         uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t p_idx, hipStream_t st);
 hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st);
-hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
-                             uint32_t head_idx, size_t upper, hipStream_t st);
-hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
-                             int shadow_rays, uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st);
-hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, size_t upper, hipStream_t st);
+// One launch over up to four queues (counter index MISS: absent): bounce rays q_ray[cur], primary rays, shadow rays of
+// set 0 and of set 1.
+hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t p_idx,
+                             uint32_t a0_idx, uint32_t a1_idx, uint32_t head_idx, size_t upper, hipStream_t st);
+// depth 0 shades the primary queue into set 1 and starts the sample: fold = 2 adds the old content of W.L (the sample
+// two passes back) to the pixel sum first, then W.L and the throughput are reset; other depths use set 0.
+hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
+                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st);
+hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set,
+                               size_t upper, hipStream_t st);
 // pixel = (sum + L_first + L_second) / n_samples; L_first may be null (a single sample pass)
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L_first,
                            const float* L_second, float* out, hipStream_t st);

@@ -407,11 +407,13 @@ __device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, ui
 
 // ------------------------------------------------------------------------------------------------
 // Stage 1: ray generation.  One lane per pixel slot of the chunk; sample (si, sj) of the regular
-// antialiasing grid (src/integrator.rs:33-48).  Also folds the previous sample's radiance into the
-// pixel sum (integrator.rs:50-53 adds the samples in generation order).
+// antialiasing grid (src/integrator.rs:33-48).  Primary rays depend on nothing but the pixel and the
+// sample index, so this stage only fills the primary queue; the per-sample reset of the pixel's
+// radiance and throughput is done by the shade launch of bounce 0 (the primary rays of a pass are
+// generated and traced while the pass before it is still in flight).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R, CameraDev cam, uint32_t chunk_begin, uint32_t chunk_n,
-                                                uint32_t si, uint32_t sj, uint32_t aa, uint32_t fold, uint32_t q_idx) {
+                                                uint32_t si, uint32_t sj, uint32_t aa, uint32_t first, uint32_t p_idx) {
     __shared__ uint32_t sh_app[STAGE_BLOCK / 64];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
@@ -419,18 +421,12 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R,
     if (i < chunk_n) valid = slot_pixel(R, chunk_begin + i, cx, cy);
     f3 pos = mk(0, 0, 0), dir = mk(0, 0, 0);
     if (valid) {
-        if (fold == 0u) {
+        if (first) {
             uint64_t seed = (uint64_t)cx ^ __builtin_bswap64((uint64_t)cy);  // integrator.rs:36
             Rng r = rng_seed(seed);
             W.rng_lo[i] = r.lo; W.rng_hi[i] = r.hi;
             W.sum[i] = 0.0f; W.sum[i + W.cap] = 0.0f; W.sum[i + 2 * W.cap] = 0.0f;
-        } else if (fold == 2u) {
-            W.sum[i] = W.sum[i] + W.L[i];
-            W.sum[i + W.cap] = W.sum[i + W.cap] + W.L[i + W.cap];
-            W.sum[i + 2 * W.cap] = W.sum[i + 2 * W.cap] + W.L[i + 2 * W.cap];
         }
-        W.L[i] = 0.0f; W.L[i + W.cap] = 0.0f; W.L[i + 2 * W.cap] = 0.0f;
-        W.beta[i] = 1.0f; W.beta[i + W.cap] = 1.0f; W.beta[i + 2 * W.cap] = 1.0f;
         float n = (float)aa;
         float x = (float)cx + ((float)si + 0.5f) / n - 0.5f;  // integrator.rs:41-42
         float y = (float)cy + ((float)sj + 0.5f) / n - 0.5f;
@@ -440,39 +436,47 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R,
         dir = normalize(d);
         pos = cam.pos;
     }
-    uint32_t q = block_append<STAGE_BLOCK / 64>(valid, &W.counts[q_idx], sh_app);
+    uint32_t q = block_append<STAGE_BLOCK / 64>(valid, &W.counts[p_idx], sh_app);
     if (valid) {
-        W.q_slot[0][q] = i;
-        float* r = W.q_ray[0];
+        W.p_slot[q] = i;
+        float* r = W.p_ray;
         r[q] = pos.x; r[q + W.cap] = pos.y; r[q + 2 * W.cap] = pos.z;
         r[q + 3 * W.cap] = dir.x; r[q + 4 * W.cap] = dir.y; r[q + 5 * W.cap] = dir.z;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 2: trace.  One persistent launch serves both ray kinds of a bounce: the closest-hit rays of
-// the current path queue (scene.root.hit(ray, 1e12), integrator.rs:64) and the shadow rays the
-// previous shade stage emitted (scene.root.is_hit(&ray, t_max), integrator.rs:124).
+// Stage 2: trace.  One persistent launch serves up to four queues: the closest-hit rays of a bounce
+// (scene.root.hit(ray, 1e12), integrator.rs:64), the primary rays of the next sample pass, and the
+// shadow rays (scene.root.is_hit(&ray, t_max), integrator.rs:124) that the shade launches before it
+// left in the two shade sets.
 // ------------------------------------------------------------------------------------------------
 struct WaveIO {
-    const float* q_ray;   // closest-hit ray queue of this bounce
-    const float* a_ray;   // shadow-ray queue
-    const uint32_t* a_vidx;
+    const float* q_ray;   // closest-hit ray queue of this bounce -> h_rec
+    const float* p_ray;   // primary rays -> p_rec
+    const float *a_ray0, *a_ray1;   // shadow-ray queues of the two shade sets (separate members: an array would be indexed through scratch memory)
+    const uint32_t *a_vidx0, *a_vidx1;
     uint4* h_rec;
-    uint8_t* vis;
+    uint4* p_rec;
+    uint8_t *vis0, *vis1;
     uint32_t cap, any_cap;
-    uint32_t n_closest;
-    // Closest-hit rays are items [0, n_closest), shadow rays follow (words 6 and 7 of a closest-hit ray
-    // are ignored and point at its first word).
+    // Items [0, n_q) are bounce rays, [n_q, n_closest) primary rays, [n_closest, n_a0) shadow rays of set 0, the rest
+    // shadow rays of set 1 (words 6 and 7 of a closest-hit ray are ignored and point at its first word).
+    uint32_t n_q, n_closest, n_a0;
     __device__ __forceinline__ void stage_addr(uint32_t i, const void* (&src)[8]) const {
         const bool a = i >= n_closest;
-        const uint32_t j = a ? i - n_closest : i;
-        const float* base = (a ? a_ray : q_ray) + j;
+        const bool second = i >= (a ? +n_a0 : +n_q);
+        const uint32_t j = i - (a ? (second ? +n_a0 : +n_closest) : (second ? +n_q : 0u));
+        // unary plus: a conditional over two members is an lvalue, and the nested choice of addresses would go through a
+        // table in scratch memory
+        const float* ra = second ? +a_ray1 : +a_ray0;
+        const float* rc = second ? +p_ray : +q_ray;
+        const float* base = (a ? ra : rc) + j;
         const size_t stride = a ? any_cap : cap;
 #pragma unroll
         for (int c = 0; c < 6; c++) src[c] = base + c * stride;
         src[6] = a ? base + 6 * stride : base;
-        src[7] = a ? (const void*)(a_vidx + j) : (const void*)base;
+        src[7] = a ? (const void*)((second ? +a_vidx1 : +a_vidx0) + j) : (const void*)base;
     }
     __device__ __forceinline__ void decode(uint32_t i, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const {
         pos = mk(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]));
@@ -482,26 +486,29 @@ struct WaveIO {
         tag = raw[7];
     }
     __device__ __forceinline__ void store_closest(uint32_t i, uint32_t, bool found, const Best& b, float) const {
-        uint4* rec = h_rec + 2 * (size_t)i;
+        uint4* rec = i >= n_q ? +p_rec + 2 * (size_t)(i - n_q) : +h_rec + 2 * (size_t)i;
         if (!found) rec[0].x = MISS;
         if (found) {
             rec[0] = make_uint4(b.obj, b.prim, __float_as_uint(b.t_local), __float_as_uint(b.u));
             rec[1].x = __float_as_uint(b.v);
         }
     }
-    __device__ __forceinline__ void store_any(uint32_t, uint32_t tag, bool occluded) const { vis[tag] = occluded ? 1 : 0; }
+    __device__ __forceinline__ void store_any(uint32_t i, uint32_t tag, bool occluded) const { (i >= n_a0 ? +vis1 : +vis0)[tag] = occluded ? 1 : 0; }
 };
 
 template <int MESHLOC, bool TAB_LDS>
-__global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_slot_idx, uint32_t a_slot_idx,
-                                                            uint32_t head_idx, uint32_t chunk_hint) {
-    // queue lengths written by the previous stages (q_slot_idx / a_slot_idx = MISS: that queue is absent)
-    const uint32_t n_closest = q_slot_idx == MISS ? 0u : W.counts[q_slot_idx];
-    const uint32_t n_any = a_slot_idx == MISS ? 0u : W.counts[a_slot_idx];
-    const uint32_t n = n_closest + n_any;
+__global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
+                                                            uint32_t a1_idx, uint32_t head_idx, uint32_t chunk_hint) {
+    // queue lengths written by the previous stages (index MISS: that queue is absent)
+    const uint32_t n_q = q_idx == MISS ? 0u : W.counts[q_idx];
+    const uint32_t n_p = p_idx == MISS ? 0u : W.counts[p_idx];
+    const uint32_t n_a0 = a0_idx == MISS ? 0u : W.counts[a0_idx];
+    const uint32_t n_a1 = a1_idx == MISS ? 0u : W.counts[a1_idx];
+    const uint32_t n_closest = n_q + n_p;
+    const uint32_t n = n_closest + n_a0 + n_a1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         W.stats[0] += n_closest;
-        W.stats[1] += n_any;
+        W.stats[1] += n_a0 + n_a1;
     }
     {   // not even the block's first wave has a batch (see trace_scheduler)
         const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64), tune_min_batch(chunk_hint));
@@ -515,7 +522,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
     LdsMesh lds;
     LdsTab ltab;
     stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
-    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.a_ray, W.a_vidx, W.h_rec, W.vis, W.cap, W.any_cap, n_closest};
+    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.p_ray, W.set[0].a_ray, W.set[1].a_ray, W.set[0].a_vidx, W.set[1].a_vidx, W.h_rec, W.p_rec,
+              W.set[0].vis, W.set[1].vis, W.cap, W.any_cap, n_q, n_closest, n_closest + n_a0};
     if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
     else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
 }
@@ -527,14 +535,19 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
 // then draw the scatter direction and append the continuation ray to the next path queue.  The
 // per-pixel random stream is consumed in exactly the order of the reference's recursion.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs W, uint32_t cur, int32_t depth, int32_t max_depth, int32_t shadow_rays,
-                                                    uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx) {
+// `T` is the shade set the launch fills.  Bounce 0 (`fold` != 0) reads the primary queue and starts the pixel's next
+// sample: fold 2 adds the radiance buffer's old content (the sample two passes back, complete by now) to the
+// pixel sum in generation order (integrator.rs:50-53), fold 1 and 2 zero the buffer; the throughput starts at 1.
+__global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
+                                                    uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx) {
     __shared__ uint32_t sh_app[STAGE_BLOCK / 64];
     const uint32_t n = W.counts[q_in_idx];
-    const float* r = cur ? W.q_ray[1] : W.q_ray[0];
-    const uint32_t* q_slot_in = cur ? W.q_slot[1] : W.q_slot[0];
-    float* q_ray_out = cur ? W.q_ray[0] : W.q_ray[1];
-    uint32_t* q_slot_out = cur ? W.q_slot[0] : W.q_slot[1];
+    const bool odd = (depth & 1) != 0;
+    const float* r = fold ? W.p_ray : (odd ? W.q_ray[1] : W.q_ray[0]);
+    const uint32_t* q_slot_in = fold ? W.p_slot : (odd ? W.q_slot[1] : W.q_slot[0]);
+    const uint4* rec_in = fold ? W.p_rec : W.h_rec;
+    float* q_ray_out = odd ? W.q_ray[0] : W.q_ray[1];
+    uint32_t* q_slot_out = odd ? W.q_slot[0] : W.q_slot[1];
     const uint32_t cap = W.cap;
     const size_t ac = W.any_cap;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -551,9 +564,18 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
             slot = q_slot_in[i];
             f3 pos = mk(r[i], r[i + cap], r[i + 2 * cap]);
             dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
-            beta = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
+            if (fold) {
+                if (fold == 2u) {
+                    W.sum[slot] = W.sum[slot] + W.L[slot];
+                    W.sum[slot + cap] = W.sum[slot + cap] + W.L[slot + cap];
+                    W.sum[slot + 2 * cap] = W.sum[slot + 2 * cap] + W.L[slot + 2 * cap];
+                }
+                W.L[slot] = 0.0f; W.L[slot + cap] = 0.0f; W.L[slot + 2 * cap] = 0.0f;
+            } else {
+                beta = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
+            }
             Best b;
-            const uint4 rec0 = W.h_rec[2 * (size_t)i];
+            const uint4 rec0 = rec_in[2 * (size_t)i];
             b.obj = rec0.x;
             if (b.obj == MISS) {  // integrator.rs:66
                 f3 c = beta * sky_color(S, dir);
@@ -561,7 +583,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
             } else {
                 hit = true;
                 b.prim = rec0.y;
-                b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = __uint_as_float(W.h_rec[2 * (size_t)i + 1].x);
+                b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = __uint_as_float(rec_in[2 * (size_t)i + 1].x);
                 f3 hp, hn;
                 float hu, hv;
                 reconstruct_hit(S, b, pos, dir, hp, hn, hu, hv);
@@ -581,8 +603,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
         Rng rng; rng.lo = 0; rng.hi = 0;
         if (hit) { rng.lo = W.rng_lo[slot]; rng.hi = W.rng_hi[slot]; }
         if (lit) {                                                     // integrator.rs:80-88
-            W.lit_slot[lq] = slot;
-            float* f = W.lit_f;
+            T.lit_slot[lq] = slot;
+            float* f = T.lit_f;
             f[lq] = beta.x; f[lq + cap] = beta.y; f[lq + 2 * cap] = beta.z;
             f[lq + 3 * cap] = diffuse.x; f[lq + 4 * cap] = diffuse.y; f[lq + 5 * cap] = diffuse.z;
         }
@@ -597,17 +619,17 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
                     float tm = 0.0f;
                     if (lit) {
                         light_sample(lt, p, nrm, rng, sd, tm, ill);
-                        float* q = W.smp + (size_t)s * 4 * cap + lq;
+                        float* q = T.smp + (size_t)s * 4 * cap + lq;
                         q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z;
                         shoot = !(tm == 0.0f);                         // integrator.rs:124
                     }
                     uint32_t aq = block_append<STAGE_BLOCK / 64>(shoot, &W.counts[any_idx], sh_app);
                     if (shoot) {
-                        float* a = W.a_ray;
+                        float* a = T.a_ray;
                         a[aq] = p.x; a[aq + ac] = p.y; a[aq + 2 * ac] = p.z;
                         a[aq + 3 * ac] = sd.x; a[aq + 4 * ac] = sd.y; a[aq + 5 * ac] = sd.z;
                         a[aq + 6 * ac] = tm;
-                        W.a_vidx[aq] = s * cap + lq;
+                        T.a_vidx[aq] = s * cap + lq;
                     }
                 }
             }
@@ -643,7 +665,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
 // Marks every queued path as a miss (max_depth = 0: integrate_recur returns the skybox at once).
 __global__ void k_mark_miss(WaveBufs W, uint32_t q_idx) {
     const uint32_t n = W.counts[q_idx];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W.h_rec[2 * (size_t)i].x = MISS;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W.p_rec[2 * (size_t)i].x = MISS;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,11 +673,11 @@ __global__ void k_mark_miss(WaveBufs W, uint32_t q_idx) {
 // src/integrator.rs:107-132) and add `diffuse * illumination` (integrator.rs:87), weighted by the
 // path throughput, to the sample's radiance.  Sums run in the reference's order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, int32_t shadow_rays, uint32_t lit_idx) {
+__global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, ShadeSet T, int32_t shadow_rays, uint32_t lit_idx) {
     const uint32_t n = W.counts[lit_idx];
     const uint32_t cap = W.cap;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const float* f = W.lit_f;
+        const float* f = T.lit_f;
         f3 beta = mk(f[j], f[j + cap], f[j + 2 * cap]);
         f3 diffuse = mk(f[j + 3 * cap], f[j + 4 * cap], f[j + 5 * cap]);
         f3 illum = fill(0.0f);
@@ -665,16 +687,16 @@ __global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, in
             int ns = light_is_delta(lt) ? 1 : shadow_rays;
             f3 total = fill(0.0f);
             for (int k = 0; k < ns; k++, s++) {
-                const float* q = W.smp + (size_t)s * 4 * cap + j;
+                const float* q = T.smp + (size_t)s * 4 * cap + j;
                 float tm = q[0];
                 f3 ill = mk(q[cap], q[2 * (size_t)cap], q[3 * (size_t)cap]);
-                bool visible = (tm == 0.0f) || (W.vis[(size_t)s * cap + j] == 0);   // integrator.rs:124
+                bool visible = (tm == 0.0f) || (T.vis[(size_t)s * cap + j] == 0);   // integrator.rs:124
                 if (visible) total = total + ill;
             }
             illum = illum + total / (float)ns;             // integrator.rs:131, :84
         }
         f3 c = beta * (diffuse * illum);
-        uint32_t slot = W.lit_slot[j];
+        uint32_t slot = T.lit_slot[j];
         W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
     }
 }
@@ -789,9 +811,9 @@ hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBa
     return hipGetLastError();
 }
 hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev& cam, uint32_t chunk_begin, uint32_t chunk_n,
-                         uint32_t si, uint32_t sj, uint32_t aa, uint32_t fold, uint32_t q_idx, hipStream_t st) {
+                         uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t p_idx, hipStream_t st) {
     uint32_t g = (chunk_n + STAGE_BLOCK - 1) / STAGE_BLOCK;
-    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(STAGE_BLOCK), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, fold, q_idx);
+    hipLaunchKernelGGL(k_raygen, dim3(g), dim3(STAGE_BLOCK), 0, st, W, R, cam, chunk_begin, chunk_n, si, sj, aa, first ? 1u : 0u, p_idx);
     return hipGetLastError();
 }
 hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st) {
@@ -801,27 +823,31 @@ hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hip
     hipLaunchKernelGGL(k_mark_miss, dim3(g), dim3(256), 0, st, W, q_idx);
     return hipGetLastError();
 }
-hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t a_idx,
-                             uint32_t head_idx, size_t upper, hipStream_t st) {
+hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
+                             uint32_t a1_idx, uint32_t head_idx, size_t upper, hipStream_t st) {
     uint32_t g = sched_grid(cfg, upper);
-    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, a_idx, head_idx, (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20));
+    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, p_idx, a0_idx, a1_idx, head_idx,
+                           (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20));
     return hipGetLastError();
 }
-hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, int depth, int max_depth,
-                             int shadow_rays, uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st) {
+hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
+                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st) {
     size_t need = (upper + STAGE_BLOCK - 1) / STAGE_BLOCK;
     size_t capg = (size_t)cfg.num_cus * (2048 / STAGE_BLOCK);
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
-    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, cur, depth, max_depth, shadow_rays, q_in, q_out, lit_idx, any_idx);
+    // bounce 0 fills shade set 1, the other bounces set 0
+    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, W.set[fold ? 1 : 0], depth, max_depth, shadow_rays, fold, q_in, q_out,
+                       lit_idx, any_idx);
     return hipGetLastError();
 }
-hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, size_t upper, hipStream_t st) {
+hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set, size_t upper,
+                               hipStream_t st) {
     size_t need = (upper + 255) / 256;
     size_t capg = (size_t)cfg.num_cus * 8;
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
-    hipLaunchKernelGGL(k_wave_resolve, dim3(g), dim3(256), 0, st, S, W, shadow_rays, lit_idx);
+    hipLaunchKernelGGL(k_wave_resolve, dim3(g), dim3(256), 0, st, S, W, W.set[set ? 1 : 0], shadow_rays, lit_idx);
     return hipGetLastError();
 }
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L_first,
