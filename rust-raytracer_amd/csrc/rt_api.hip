@@ -615,7 +615,12 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     uint32_t S_total = 0;
-    for (const auto& l : ctx->lights) S_total += light_samples(l, integ->shadow_rays);
+    uint32_t S_shoot = 0;   // of those, the samples that can need a shadow ray
+    for (const auto& l : ctx->lights) {
+        const uint32_t ns = light_samples(l, integ->shadow_rays);
+        S_total += ns;
+        if (!(l.kind == RTAMD_LIGHT_AMBIENT || (l.kind == RTAMD_LIGHT_AO && l.param == 0.0f))) S_shoot += ns;
+    }
     const size_t total_slots = rtamd_region_pixels(region);
     if (total_slots == 0) return RTAMD_OK;
     if (total_slots > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "region too large");
@@ -697,7 +702,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     launches++;
                     if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
                         HIP_TRY(ctx, launch_mark_miss(W, cb + CS::PQ, chunk_n, st));
-                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, 1, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, 1, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, chunk_n, st));
                         launches += 2;
                         continue;
                     }
@@ -714,7 +719,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     }
                 }
                 timed_begin(ctx, 2, st);
-                HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, D, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, chunk_n, st));
+                HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, D, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, chunk_n, st));
                 timed_end(ctx, st);
                 launches++;
                 for (int d = 1; d < D; d++) {
@@ -741,7 +746,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     }
                     HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, sr, cb + CS::LIT + (d - 1), d == 1 ? 1u : 0u, chunk_n, st));
                     launches++;
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, S_shoot, chunk_n, st));
                     timed_end(ctx, st);
                     launches++;
                 }

@@ -104,8 +104,9 @@ hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const Wave
                              uint32_t a0_idx, uint32_t a1_idx, uint32_t head_idx, size_t upper, hipStream_t st);
 // depth 0 shades the primary queue into set 1 and starts the sample: fold = 2 adds the old content of W.L (the sample
 // two passes back) to the pixel sum first, then W.L and the throughput are reset; other depths use set 0.
+// n_shoot: shadow rays per lit hit = light samples of the lights that can need one (not ambient, not reach 0).
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
-                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st);
+                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, size_t upper, hipStream_t st);
 hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set,
                                size_t upper, hipStream_t st);
 // pixel = (sum + L_first + L_second) / n_samples; L_first may be null (a single sample pass)

@@ -393,6 +393,50 @@ __device__ __forceinline__ uint32_t block_append(bool take, uint32_t* counter, u
     return sh[wave] + before;
 }
 
+// As block_append, and also hands out the range the whole block got (`base`, `count`), so that a second queue whose
+// entries are a fixed multiple `mult` of this one's needs no counter traffic of its own beyond one fire-and-forget
+// add of count * mult to `counter2`.  `sh` holds two words more than one per wave.
+template <int NWAVES>
+__device__ __forceinline__ uint32_t block_append_range(bool take, uint32_t* counter, uint32_t* counter2, uint32_t mult, uint32_t* sh, uint32_t& base_out,
+                                                       uint32_t& count_out) {
+    static_assert(NWAVES <= 62, "one scan lane per wave");
+    unsigned long long mask = __ballot(take);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t before = __popcll(mask & ((1ULL << lane) - 1ULL));
+    if (lane == 0) sh[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t v = lane < (uint32_t)NWAVES ? sh[lane] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < NWAVES; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        const uint32_t sum = __shfl(incl, NWAVES - 1);
+        uint32_t base = 0;
+        if (lane == 0 && sum) {
+            base = atomicAdd(counter, sum);
+            if (mult) atomicAdd(counter2, sum * mult);   // result unused: no wait
+        }
+        base = __shfl(base, 0);
+        if (lane < (uint32_t)NWAVES) sh[lane] = base + incl - v;
+        if (lane == 0) { sh[NWAVES] = base; sh[NWAVES + 1] = sum; }
+    }
+    __syncthreads();
+    base_out = sh[NWAVES];
+    count_out = sh[NWAVES + 1];
+    return sh[wave] + before;
+}
+
+// Whether a sample of the light can need a shadow ray at all (illumination() skips the occlusion test where the
+// light's t_max is 0, integrator.rs:124): an ambient light never does, an occlusion light of reach 0 neither.
+__device__ __forceinline__ bool light_shoots(const DevLight& l) {
+    if (l.kind == LIGHT_AMBIENT) return false;
+    if (l.kind == LIGHT_AO) return !(l.param == 0.0f);
+    return true;
+}
+
 // Pixel slot -> pixel coordinates of the owned tile set (see rtamd_region).
 __device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, uint32_t& cx, uint32_t& cy) {
     uint32_t per_tile = R.tile_w * R.tile_h;
@@ -539,8 +583,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
 // sample: fold 2 adds the radiance buffer's old content (the sample two passes back, complete by now) to the
 // pixel sum in generation order (integrator.rs:50-53), fold 1 and 2 zero the buffer; the throughput starts at 1.
 __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
-                                                    uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx) {
-    __shared__ uint32_t sh_app[STAGE_BLOCK / 64];
+                                                    uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot) {
+    __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
     const uint32_t n = W.counts[q_in_idx];
     const bool odd = (depth & 1) != 0;
     const float* r = fold ? W.p_ray : (odd ? W.q_ray[1] : W.q_ray[0]);
@@ -597,7 +641,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
                 lit = !is_zero(diffuse);                               // integrator.rs:80
             }
         }
-        uint32_t lq = block_append<STAGE_BLOCK / 64>(lit, &W.counts[lit_idx], sh_app);
+        // Every lit hit emits the same number of shadow rays (`n_shoot`, the samples of the lights that can need one), so
+        // the shadow-ray queue needs no compaction of its own: the block's rays go to [lbase * n_shoot, (lbase + lcnt) *
+        // n_shoot), grouped by sample.
+        uint32_t lbase, lcnt;
+        uint32_t lq = block_append_range<STAGE_BLOCK / 64>(lit, &W.counts[lit_idx], &W.counts[any_idx], n_shoot, sh_app, lbase, lcnt);
         // ---- phase B: draw light samples, then the scatter direction (same stream order) ----
         f3 next_pos = mk(0, 0, 0), next_dir = mk(0, 0, 0);
         Rng rng; rng.lo = 0; rng.hi = 0;
@@ -609,28 +657,30 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
             f[lq + 3 * cap] = diffuse.x; f[lq + 4 * cap] = diffuse.y; f[lq + 5 * cap] = diffuse.z;
         }
         {
-            uint32_t s = 0;
+            uint32_t s = 0, s_shoot = 0;
             for (uint32_t l = 0; l < S.n_lights; l++) {
                 const DevLight lt = S.lights[l];
                 const int ns = light_is_delta(lt) ? 1 : shadow_rays;
+                const bool shoots = light_shoots(lt);
                 for (int k = 0; k < ns; k++, s++) {
-                    bool shoot = false;
-                    f3 sd = mk(0, 0, 0), ill = mk(0, 0, 0);
-                    float tm = 0.0f;
                     if (lit) {
+                        f3 sd, ill;
+                        float tm;
                         light_sample(lt, p, nrm, rng, sd, tm, ill);
                         float* q = T.smp + (size_t)s * 4 * cap + lq;
                         q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z;
-                        shoot = !(tm == 0.0f);                         // integrator.rs:124
+                        // A sample with t_max = 0 of a light that can shoot (a point light at distance exactly 0) is queued
+                        // as a zero-length ray, which nothing occludes; the resolve stage takes it as visible either way.
+                        if (shoots) {
+                            const size_t aq = (size_t)lbase * n_shoot + (size_t)s_shoot * lcnt + (lq - lbase);
+                            float* a = T.a_ray;
+                            a[aq] = p.x; a[aq + ac] = p.y; a[aq + 2 * ac] = p.z;
+                            a[aq + 3 * ac] = sd.x; a[aq + 4 * ac] = sd.y; a[aq + 5 * ac] = sd.z;
+                            a[aq + 6 * ac] = tm;
+                            T.a_vidx[aq] = s * cap + lq;
+                        }
                     }
-                    uint32_t aq = block_append<STAGE_BLOCK / 64>(shoot, &W.counts[any_idx], sh_app);
-                    if (shoot) {
-                        float* a = T.a_ray;
-                        a[aq] = p.x; a[aq + ac] = p.y; a[aq + 2 * ac] = p.z;
-                        a[aq + 3 * ac] = sd.x; a[aq + 4 * ac] = sd.y; a[aq + 5 * ac] = sd.z;
-                        a[aq + 6 * ac] = tm;
-                        T.a_vidx[aq] = s * cap + lq;
-                    }
+                    if (shoots) s_shoot++;
                 }
             }
         }
@@ -831,14 +881,14 @@ hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const Wave
     return hipGetLastError();
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
-                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, size_t upper, hipStream_t st) {
+                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, size_t upper, hipStream_t st) {
     size_t need = (upper + STAGE_BLOCK - 1) / STAGE_BLOCK;
     size_t capg = (size_t)cfg.num_cus * (2048 / STAGE_BLOCK);
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
     // bounce 0 fills shade set 1, the other bounces set 0
     hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, W.set[fold ? 1 : 0], depth, max_depth, shadow_rays, fold, q_in, q_out,
-                       lit_idx, any_idx);
+                       lit_idx, any_idx, n_shoot);
     return hipGetLastError();
 }
 hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set, size_t upper,
