@@ -182,7 +182,9 @@ typedef struct rtamd_camera {
 } rtamd_camera;
 
 /* Integrator parameters: replaces WhittedIntegrator, src/integrator.rs:12-19 (gamma is unused by
- * the reference and absent here). */
+ * the reference and absent here).  scatter_rays = 1 (what src/main.rs uses) runs the wavefront
+ * pipeline; any other value runs a depth-first kernel, one pixel per lane, which keeps the order in
+ * which the recursion of src/integrator.rs:90-102 draws from the pixel's random stream. */
 typedef struct rtamd_integrator {
     int32_t max_depth, shadow_rays, scatter_rays, antialiasing;
 } rtamd_integrator;

@@ -596,6 +596,60 @@ int rtamd_trace_any(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_
     return RTAMD_OK;
 }
 
+namespace {
+CameraDev make_camera(const rtamd_camera& cam) {
+    CameraDev C;
+    C.pos = f3{cam.pos[0], cam.pos[1], cam.pos[2]};
+    C.dir = f3{cam.dir[0], cam.dir[1], cam.dir[2]};
+    C.horizontal = f3{cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]};
+    C.vertical = f3{cam.vertical[0], cam.vertical[1], cam.vertical[2]};
+    C.width = cam.width; C.height = cam.height;
+    return C;
+}
+
+// scatter_rays != 1: the path tree of a pixel is walked depth first by one lane (k_pixel_depth_first), which keeps the
+// reference's random-stream order; the wavefront pipeline below covers scatter_rays = 1.
+int render_depth_first(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, size_t total_slots,
+                       float* out, rtamd_stats* stats) {
+    const int D = integ->max_depth > 0 ? integ->max_depth : 0;
+    const size_t cap = std::min(total_slots, ctx->max_paths);
+    const size_t stack_words = (size_t)(D ? D : 1) * 20 * cap;
+    int rc = ensure_batch(ctx, 256 + stack_words * 4);
+    if (rc) return rc;
+    unsigned long long* dstats = (unsigned long long*)ctx->batch_buf;
+    float* stack = (float*)((char*)ctx->batch_buf + 256);
+    const RegionDev R = make_region(*region);
+    const CameraDev C = make_camera(*cam);
+    hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(dstats, 0, 16, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    uint64_t launches = 0;
+    for (size_t begin = 0; begin < total_slots; begin += cap) {
+        const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
+        HIP_TRY(ctx, launch_pixel_depth_first(ctx->S, ctx->cfg, R, C, D, integ->shadow_rays, integ->scatter_rays, (uint32_t)integ->antialiasing,
+                                              (uint32_t)begin, chunk_n, stack, (uint32_t)cap, out, dstats, ctx->stream));
+        launches++;
+    }
+    HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, dstats, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    ctx->event_pool.push_back(ev0);
+    ctx->event_pool.push_back(ev1);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->closest_rays = h[0];
+        stats->any_rays = h[1];
+        stats->paths = owned_pixels(*region) * (uint64_t)integ->antialiasing * integ->antialiasing;
+        stats->launches = launches;
+        stats->device_ms = ms;
+    }
+    return RTAMD_OK;
+}
+}  // namespace
+
 size_t rtamd_region_pixels(const rtamd_region* region) {
     if (!region_ok(region)) return 0;
     return owned_tiles(*region) * (size_t)region->tile_w * region->tile_h;
@@ -609,7 +663,6 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     if (region->x0 + (uint64_t)region->w > cam->width || region->y0 + (uint64_t)region->h > cam->height)
         return fail(ctx, RTAMD_E_INVALID, "region exceeds the camera image");
     if (integ->antialiasing < 1) return fail(ctx, RTAMD_E_INVALID, "antialiasing must be >= 1");
-    if (integ->scatter_rays != 1) return fail(ctx, RTAMD_E_UNSUPPORTED, "only scatter_rays = 1 is supported on the device");
     if (integ->shadow_rays < 1) return fail(ctx, RTAMD_E_INVALID, "shadow_rays must be >= 1");
     if (integ->max_depth > (int)CounterSlots::MAX_DEPTH) return fail(ctx, RTAMD_E_INVALID, "max_depth above 64 is not supported");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -624,6 +677,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     const size_t total_slots = rtamd_region_pixels(region);
     if (total_slots == 0) return RTAMD_OK;
     if (total_slots > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "region too large");
+    if (integ->scatter_rays != 1) return render_depth_first(ctx, cam, integ, region, total_slots, out, stats);
     // pixel groups: at most n_streams in flight, none smaller than 64 Ki pixels unless the region is
     const size_t G = (size_t)ctx->n_streams;
     size_t cap = (total_slots + G - 1) / G;
@@ -638,12 +692,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
         if (rc) return rc;
     }
     RegionDev R = make_region(*region);
-    CameraDev C;
-    C.pos = f3{cam->pos[0], cam->pos[1], cam->pos[2]};
-    C.dir = f3{cam->dir[0], cam->dir[1], cam->dir[2]};
-    C.horizontal = f3{cam->horizontal[0], cam->horizontal[1], cam->horizontal[2]};
-    C.vertical = f3{cam->vertical[0], cam->vertical[1], cam->vertical[2]};
-    C.width = cam->width; C.height = cam->height;
+    const CameraDev C = make_camera(*cam);
 
     hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
     HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));

@@ -112,6 +112,11 @@ hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const Wa
 // pixel = (sum + L_first + L_second) / n_samples; L_first may be null (a single sample pass)
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L_first,
                            const float* L_second, float* out, hipStream_t st);
+// The whole integrator, depth first, one lane per pixel slot (any scatter_rays).  stack: max_depth * 20 * cap floats;
+// out: the chunk's pixels (3 floats per slot, written for every slot); stats[0..1] += closest-hit / any-hit rays.
+hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, const RegionDev& R, const CameraDev& cam, int max_depth, int shadow_rays,
+                                    int scatter_rays, uint32_t aa, uint32_t chunk_begin, uint32_t chunk_n, float* stack, uint32_t cap, float* out,
+                                    unsigned long long* stats, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 #ifdef RTAMD_DIAG
 hipError_t diag_read(unsigned long long* out, int reset);

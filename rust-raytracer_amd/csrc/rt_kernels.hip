@@ -775,6 +775,161 @@ __global__ __launch_bounds__(256) void k_finalize(WaveBufs W, RegionDev R, uint3
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Depth-first form of the integrator for scatter_rays != 1.  The reference's recursion draws the random numbers of a
+// whole scatter subtree before the next scatter ray of the same hit (integrator.rs:90-102), an order that a
+// breadth-first wavefront cannot reproduce; here one lane owns one pixel and walks its path tree with an explicit
+// stack, so the stream order and the nested summation `color += scatter * L / scatter_rays` are the reference's.
+// The stack lives in HBM, component-major: word f of the frame of depth d of pixel slot i at [(d * FRAME + f) * cap + i].
+// ------------------------------------------------------------------------------------------------
+struct PathFrame {
+    static constexpr uint32_t WORDS = 20;
+    f3 color, w, n, dir, p_out, p_in;
+    uint32_t mat;
+    int32_t k;   // scatter rays drawn so far
+};
+__device__ __forceinline__ void frame_store(float* stack, size_t cap, uint32_t i, int d, const PathFrame& f) {
+    float* q = stack + (size_t)d * PathFrame::WORDS * cap + i;
+    const float v[PathFrame::WORDS] = {f.color.x, f.color.y, f.color.z, f.w.x, f.w.y, f.w.z, f.n.x, f.n.y, f.n.z, f.dir.x, f.dir.y, f.dir.z,
+                                       f.p_out.x, f.p_out.y, f.p_out.z, f.p_in.x, f.p_in.y, f.p_in.z, __uint_as_float(f.mat), __int_as_float(f.k)};
+#pragma unroll
+    for (uint32_t c = 0; c < PathFrame::WORDS; c++) q[c * cap] = v[c];
+}
+__device__ __forceinline__ void frame_load(const float* stack, size_t cap, uint32_t i, int d, PathFrame& f) {
+    const float* q = stack + (size_t)d * PathFrame::WORDS * cap + i;
+    float v[PathFrame::WORDS];
+#pragma unroll
+    for (uint32_t c = 0; c < PathFrame::WORDS; c++) v[c] = q[c * cap];
+    f.color = mk(v[0], v[1], v[2]); f.w = mk(v[3], v[4], v[5]); f.n = mk(v[6], v[7], v[8]); f.dir = mk(v[9], v[10], v[11]);
+    f.p_out = mk(v[12], v[13], v[14]); f.p_in = mk(v[15], v[16], v[17]);
+    f.mat = __float_as_uint(v[18]); f.k = __float_as_int(v[19]);
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_pixel_depth_first(DevScene S, RegionDev R, CameraDev cam, int32_t max_depth, int32_t shadow_rays, int32_t scatter_rays,
+                                                           uint32_t aa, uint32_t chunk_begin, uint32_t chunk_n, float* stack, uint32_t cap, float* out,
+                                                           unsigned long long* stats) {
+    LdsMem mem;
+    const LdsMem* lm = stage_mesh<USE_LDS>(S, mem);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_closest = 0, n_any = 0;
+    if (i < chunk_n) {
+        uint32_t cx = 0, cy = 0;
+        const bool valid = slot_pixel(R, chunk_begin + i, cx, cy);
+        f3 total = fill(0.0f);
+        if (valid) {
+            Rng rng = rng_seed((uint64_t)cx ^ __builtin_bswap64((uint64_t)cy));  // integrator.rs:36
+            for (uint32_t pass = 0; pass < aa * aa; pass++) {
+                const uint32_t si = pass / aa, sj = pass % aa;
+                const float n = (float)aa;
+                const float x = (float)cx + ((float)si + 0.5f) / n - 0.5f;  // integrator.rs:41-42
+                const float y = (float)cy + ((float)sj + 0.5f) / n - 0.5f;
+                const float u = 2.0f * (x / (float)cam.width) - 1.0f;       // scene.rs:84-90
+                const float v = 2.0f * (y / (float)cam.height) - 1.0f;
+                f3 rpos = cam.pos;
+                f3 rdir = normalize((cam.dir + u * cam.horizontal) + v * cam.vertical);
+                enum { ENTER, SCATTER, RETURN };
+                int state = ENTER, d = 0;
+                f3 ret = fill(0.0f);
+                PathFrame cur;
+                cur.color = cur.w = cur.n = cur.dir = cur.p_out = cur.p_in = fill(0.0f); cur.mat = 0; cur.k = 0;
+                for (;;) {
+                    if (state == ENTER) {               // integrate_recur(ray, d), integrator.rs:58-88
+                        bool ends = true;
+                        if (d < max_depth) {
+                            Best b;
+                            b.obj = MISS; b.prim = 0; b.t_local = 0.f; b.u = 0.f; b.v = 0.f;
+                            float t_hit;
+                            n_closest++;
+                            if (scene_closest(S, lm, rpos, rdir, 1e12f, b, t_hit)) {
+                                ends = false;
+                                f3 hp, hn;
+                                float hu, hv;
+                                reconstruct_hit(S, b, rpos, rdir, hp, hn, hu, hv);
+                                cur.mat = S.objects[b.obj].material;
+                                cur.n = normalize(hn);
+                                const bool outside = dot(cur.n, -rdir) > 0.0f;
+                                cur.p_out = hp + cur.n * 0.001f;
+                                cur.p_in = hp - cur.n * 0.001f;
+                                cur.dir = rdir;
+                                cur.color = fill(0.0f);
+                                cur.k = 0;
+                                const f3 p = outside ? cur.p_out : cur.p_in;
+                                const f3 diffuse = material_diffuse(S.materials[cur.mat]);
+                                if (!is_zero(diffuse)) {
+                                    f3 illum = fill(0.0f);
+                                    for (uint32_t l = 0; l < S.n_lights; l++) {   // illumination(), integrator.rs:107-132
+                                        const DevLight lt = S.lights[l];
+                                        const int ns = light_is_delta(lt) ? 1 : shadow_rays;
+                                        f3 tot = fill(0.0f);
+                                        for (int k = 0; k < ns; k++) {
+                                            f3 sd, ill;
+                                            float tm;
+                                            light_sample(lt, p, cur.n, rng, sd, tm, ill);
+                                            bool visible = tm == 0.0f;
+                                            if (!visible) {
+                                                n_any++;
+                                                visible = !scene_any(S, lm, p, sd, tm);
+                                            }
+                                            if (visible) tot = tot + ill;
+                                        }
+                                        illum = illum + tot / (float)ns;
+                                    }
+                                    cur.color = cur.color + diffuse * illum;
+                                }
+                                state = SCATTER;
+                            }
+                        }
+                        if (ends) {                     // integrator.rs:59-61, :66
+                            ret = sky_color(S, rdir);
+                            state = RETURN;
+                        }
+                    } else if (state == SCATTER) {      // integrator.rs:90-102
+                        bool descend = false;
+                        while (cur.k < scatter_rays) {
+                            cur.k++;
+                            f3 o, w;
+                            if (material_scatter(S.materials[cur.mat], cur.n, cur.dir, rng, o, w)) {
+                                cur.w = w;
+                                rpos = dot(o, cur.n) > 0.0f ? cur.p_out : cur.p_in;
+                                rdir = o;
+                                frame_store(stack, cap, i, d, cur);
+                                d++;
+                                state = ENTER;
+                                descend = true;
+                                break;
+                            }
+                        }
+                        if (!descend) {
+                            ret = cur.color;
+                            state = RETURN;
+                        }
+                    } else {                            // the call at depth d returned `ret`
+                        if (d == 0) break;
+                        d--;
+                        frame_load(stack, cap, i, d, cur);
+                        cur.color = cur.color + (cur.w * ret) / (float)scatter_rays;
+                        state = SCATTER;
+                    }
+                }
+                total = total + ret;                    // integrator.rs:50-53
+            }
+            total = total / (float)(aa * aa);
+        }
+        const size_t o = 3 * (size_t)(chunk_begin + i);
+        out[o] = total.x; out[o + 1] = total.y; out[o + 2] = total.z;
+    }
+    // ray counts: one pair of atomics per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n_closest += __shfl_down(n_closest, off);
+        n_any += __shfl_down(n_any, off);
+    }
+    if ((threadIdx.x & 63u) == 0 && (n_closest | n_any)) {
+        atomicAdd(&stats[0], n_closest);
+        atomicAdd(&stats[1], n_any);
+    }
+}
+
 __global__ void k_quantize(const float* rgb, size_t n, uint8_t* out) {  // src/render.rs:62-72
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -904,6 +1059,18 @@ hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk
                            const float* L_second, float* out, hipStream_t st) {
     uint32_t g = (chunk_n + 255) / 256;
     hipLaunchKernelGGL(k_finalize, dim3(g), dim3(256), 0, st, W, R, chunk_begin, chunk_n, n_samples, L_first, L_second, out);
+    return hipGetLastError();
+}
+hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, const RegionDev& R, const CameraDev& cam, int max_depth, int shadow_rays,
+                                    int scatter_rays, uint32_t aa, uint32_t chunk_begin, uint32_t chunk_n, float* stack, uint32_t cap, float* out,
+                                    unsigned long long* stats, hipStream_t st) {
+    if (chunk_n == 0) return hipSuccess;
+    const bool lds = cfg.use_lds && S.lds_mesh != MISS;
+    const uint32_t g = (chunk_n + 255) / 256;
+    if (lds) hipLaunchKernelGGL(k_pixel_depth_first<true>, dim3(g), dim3(256), S.lds_bytes, st, S, R, cam, max_depth, shadow_rays, scatter_rays, aa, chunk_begin,
+                                chunk_n, stack, cap, out, stats);
+    else hipLaunchKernelGGL(k_pixel_depth_first<false>, dim3(g), dim3(256), 0, st, S, R, cam, max_depth, shadow_rays, scatter_rays, aa, chunk_begin,
+                            chunk_n, stack, cap, out, stats);
     return hipGetLastError();
 }
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st) {

@@ -52,6 +52,33 @@ def test_render_matches_oracle(pair, params):
     assert st["paths"] == img.shape[0] * img.shape[1] * params["antialiasing"] ** 2
 
 
+@pytest.mark.parametrize("params", [
+    dict(max_depth=3, shadow_rays=1, scatter_rays=2, antialiasing=2),
+    dict(max_depth=4, shadow_rays=2, scatter_rays=3, antialiasing=1),
+    dict(max_depth=3, shadow_rays=1, scatter_rays=0, antialiasing=2),   # direct lighting only
+    dict(max_depth=5, shadow_rays=1, scatter_rays=1, antialiasing=2),   # wavefront path, for the cross-check below
+])
+def test_branching_scatter_rays_match_oracle(rt, pair, params):
+    """scatter_rays != 1 runs the depth-first kernel (the recursion's random-stream order and nested sums)."""
+    gpu, cpu, cam = pair
+    img, st = gpu.render(**params)
+    ref, _, cnt = cpu.render(**params)
+    compare(img, ref)
+    assert abs(st["closest_rays"] - cnt["closest_rays"]) <= 2e-3 * max(1, cnt["closest_rays"])
+    assert abs(st["any_rays"] - cnt["any_rays"]) <= 2e-3 * max(1, cnt["any_rays"])
+    if params["scatter_rays"] != 1:
+        # tiles and chunking leave the pixels bit-identical here too
+        W, H = cam
+        image = np.zeros((H, W, 3), np.float32)
+        gpu.set_option(rt.OPT_MAX_PATHS, 5000)
+        for rank in range(2):
+            region = rt.Scene.make_region(W, H, tile=(64, 48), tile_first=rank, tile_stride=2)
+            tiles, _ = gpu.render(region=region, **params)
+            rt.assemble_tiles(tiles, region, rank, 2, image)
+        gpu.set_option(rt.OPT_MAX_PATHS, 1 << 22)
+        assert np.array_equal(image.view(np.uint32), img.view(np.uint32))
+
+
 def test_tiles_equal_full_frame_bitwise(rt, pair):
     """Any tile decomposition yields identical pixels: the seed depends only on (cx, cy)."""
     gpu, _, cam = pair

@@ -201,6 +201,6 @@ def test_errors_are_reported_not_fatal(rt, sky):
         s.trace_closest(np.zeros((7, 4), np.float32))  # not uploaded
     s.upload(0)
     with pytest.raises(rt.RtamdError):
-        s.render(scatter_rays=2)  # unsupported on the device: error code, no abort
+        s.render(antialiasing=0)  # invalid parameter: error code, no abort
     with pytest.raises(rt.RtamdError):
         s.render(region=rt.Scene.make_region(64, 64, rect=(0, 0, 128, 64)))  # outside the camera image
