@@ -118,15 +118,28 @@ typedef struct rtamd_root_item {
     uint32_t index; /* objects[] or trees[] */
 } rtamd_root_item;
 
-/* Materials: replaces the Material impls of src/material.rs:17-141 (constant-colour textures).
- *   NULL: green diffuse; METAL; GLOSSY(p0 = exponent, p1 = mirror fraction, color);
- *   TRANSPARENT(p0 = index of refraction); LAMBERT(color). */
+/* Textures: replaces the Texture impls of src/texture.rs:10-47,70-82.
+ *   COLOR: the material's `color`; UV: (u, v, 0); CHECKERBOARD(tex_param = repeats);
+ *   IMAGE(tex_param = index into rtamd_scene_desc::images, nearest texel). */
+enum rtamd_texture_kind { RTAMD_TEX_COLOR = 0, RTAMD_TEX_UV = 1, RTAMD_TEX_CHECKERBOARD = 2, RTAMD_TEX_IMAGE = 3 };
+
+/* Materials: replaces the Material impls of src/material.rs:17-141.
+ *   NULL: green diffuse; METAL; GLOSSY(p0 = exponent, p1 = mirror fraction, texture);
+ *   TRANSPARENT(p0 = index of refraction; Glass = 1.5, material.rs:72-78); LAMBERT(texture). */
 enum rtamd_material_kind { RTAMD_MAT_NULL = 0, RTAMD_MAT_METAL = 1, RTAMD_MAT_GLOSSY = 2, RTAMD_MAT_TRANSPARENT = 3, RTAMD_MAT_LAMBERT = 4 };
 typedef struct rtamd_material {
     uint32_t kind;
     float p0, p1;
     float color[3];
+    uint32_t tex_kind;   /* rtamd_texture_kind of Lambartian<T> / Glossy<T> */
+    int32_t tex_param;
 } rtamd_material;
+
+/* Decoded RGB8 image of a texture::Image, src/texture.rs:49-68 (row-major, 3 bytes per texel). */
+typedef struct rtamd_image {
+    const uint8_t* rgb;
+    uint32_t w, h;
+} rtamd_image;
 
 /* Lights: replaces the Light impls of src/light.rs:12-158.  emission = color * intensity.
  *   AMBIENT; DIRECTION(vec = normalised direction, param = spread, <= 0: none);
@@ -152,6 +165,7 @@ typedef struct rtamd_scene_desc {
     const rtamd_material* materials;    uint32_t n_materials;
     const rtamd_light* lights;          uint32_t n_lights;
     const uint8_t* skybox_rgb;          uint32_t sky_w, sky_h;
+    const rtamd_image* images;          uint32_t n_images;   /* image textures of the materials (may be empty) */
 } rtamd_scene_desc;
 
 /* ---- ray batches ------------------------------------------------------------------------------- */

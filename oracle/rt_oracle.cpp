@@ -166,11 +166,29 @@ float fresnel(V3 normal, V3 i, float ior) {
     }
     return 1.0f;
 }
-Color Material::sample_at(float, float) const {
+static inline int32_t sat_i32(float x) {  // Rust `as i32`: saturating, NaN -> 0
+    if (!(x == x)) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+Color Texture::color_at(float u, float v) const {
+    switch (kind) {
+        case TEX_UV: return Color(u, v, 0.0f);                    // texture.rs:22-26
+        case TEX_CHECKERBOARD: {                                  // texture.rs:36-47
+            int32_t i = sat_i32(u * (float)repeats);
+            int32_t j = sat_i32(v * (float)repeats);
+            return ((i % 2 == 0) ^ (j % 2 == 0)) ? Color(0.f, 0.f, 0.f) : Color(1.f, 1.f, 1.f);
+        }
+        case TEX_IMAGE: return image->color_at(u, v);             // texture.rs:70-82
+        default: return color;                                    // texture.rs:14-18
+    }
+}
+Color Material::sample_at(float u, float v) const {
     switch (kind) {
         case MAT_NULL: return Color(0.f, 1.f, 0.f);               // material.rs:19-23
-        case MAT_LAMBERT: return color;                          // :137-141
-        case MAT_GLOSSY: return color * (1.0f - p1);             // :41-43
+        case MAT_LAMBERT: return tex.color_at(u, v);             // :137-141
+        case MAT_GLOSSY: return tex.color_at(u, v) * (1.0f - p1);  // :41-43
         default: return Color(0.f, 0.f, 0.f);                    // Metal/Transparent/Glass
     }
 }

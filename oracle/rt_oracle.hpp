@@ -137,12 +137,21 @@ struct Image {  // texture.rs:49-82
     Color color_at(float u, float v) const;
 };
 
+enum TextureKind { TEX_COLOR = 0, TEX_UV = 1, TEX_CHECKERBOARD = 2, TEX_IMAGE = 3 };
+struct Texture {  // texture.rs:10-47, :70-82
+    int kind = TEX_COLOR;
+    Color color = Color(1.f, 1.f, 1.f);   // impl Texture for Color, texture.rs:14-18
+    int repeats = 0;                       // Checkerboard(i32), texture.rs:28-34
+    std::shared_ptr<const Image> image;    // texture::Image
+    Color color_at(float u, float v) const;
+};
+
 enum MaterialKind { MAT_NULL = 0, MAT_METAL = 1, MAT_GLOSSY = 2, MAT_TRANSPARENT = 3, MAT_LAMBERT = 4 };
-struct Material {  // material.rs:7-141 (constant-colour textures only)
+struct Material {  // material.rs:7-141
     int kind = MAT_NULL;
     float p0 = 0.f;  // Glossy exponent | Transparent ior
     float p1 = 0.f;  // Glossy mirror fraction
-    Color color = Color(1.f, 1.f, 1.f);
+    Texture tex;     // Lambartian<T>.0 / Glossy<T>.2
     Color sample_at(float u, float v) const;
     bool scatter(V3 n, V3 i, SmallRng& rng, V3& out, Color& w) const;
 };

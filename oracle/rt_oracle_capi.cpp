@@ -54,8 +54,14 @@ std::vector<Light> main_lights() {  // main.rs:67-76
 
 Material mat_transparent(float ior) { Material m; m.kind = MAT_TRANSPARENT; m.p0 = ior; return m; }
 Material mat_metal() { Material m; m.kind = MAT_METAL; return m; }
-Material mat_lambert(Color c) { Material m; m.kind = MAT_LAMBERT; m.color = c; return m; }
-Material mat_glossy(float e, float k, Color c) { Material m; m.kind = MAT_GLOSSY; m.p0 = e; m.p1 = k; m.color = c; return m; }
+Texture tex_color(Color c) { Texture t; t.color = c; return t; }
+Texture tex_uv() { Texture t; t.kind = TEX_UV; return t; }
+Texture tex_checkerboard(int repeats) { Texture t; t.kind = TEX_CHECKERBOARD; t.repeats = repeats; return t; }
+Texture tex_image(std::shared_ptr<const Image> img) { Texture t; t.kind = TEX_IMAGE; t.image = img; return t; }
+Material mat_lambert(Texture t) { Material m; m.kind = MAT_LAMBERT; m.tex = t; return m; }
+Material mat_lambert(Color c) { return mat_lambert(tex_color(c)); }
+Material mat_glossy(float e, float k, Texture t) { Material m; m.kind = MAT_GLOSSY; m.p0 = e; m.p1 = k; m.tex = t; return m; }
+Material mat_glossy(float e, float k, Color c) { return mat_glossy(e, k, tex_color(c)); }
 
 // splitmix64: the generator of the synthetic scenes (shared definition with the product's host code:
 // state += 0x9E3779B97F4A7C15; z = (z ^ z>>30) * 0xBF58476D1CE4E5B9; z = (z ^ z>>27) * 0x94D049BB133111EB; z ^ z>>31;
@@ -145,6 +151,44 @@ void* orc_scene_spheres(int n, uint64_t seed, const uint8_t* sky_rgb, int sky_w,
     s->make_camera((size_t)cam_w, (size_t)cam_h);
     s->scene.root = list;
     s->scene.skybox = make_sky(sky_rgb, sky_w, sky_h);
+    s->scene.lights = main_lights();
+    return s;
+}
+
+// Synthetic: every texture and the materials main.rs leaves out, in a plain GeometryList (same construction as the
+// product's host-side scene of that name): UV-textured mesh, checkerboard sphere, glossy image-textured sphere (tex,
+// or the skybox image), Glass sphere, standalone checkerboard triangle, checkerboard floor.
+void* orc_scene_textured(const char* ply_path, const uint8_t* sky_rgb, int sky_w, int sky_h, const uint8_t* tex_rgb, int tex_w, int tex_h, int cam_w,
+                         int cam_h) {
+    auto* s = new OrcScene();
+    std::vector<V3> verts;
+    std::vector<std::array<uint32_t, 3>> faces;
+    if (!load_ply(ply_path, verts, faces, s->error)) { fprintf(stderr, "orc: %s\n", s->error.c_str()); delete s; return nullptr; }
+    s->mesh = Mesh::from_vertices(verts, faces);
+    GeomPtr tmesh = TransformBuilder(s->mesh).scale(20.0f).rotate(V3(1.f, 0.f, 0.f), 90.0f * (PI_F / 180.0f)).build();
+    AABB bb = tmesh->bounding_box();
+    V3 c = (bb.min + bb.max) / 2.0f;
+    auto sky = make_sky(sky_rgb, sky_w, sky_h);
+    std::shared_ptr<const Image> timg = (tex_rgb && tex_w > 0 && tex_h > 0) ? make_sky(tex_rgb, tex_w, tex_h) : sky;
+    const bool have_image = (tex_rgb && tex_w > 0 && tex_h > 0) || (sky_rgb && sky_w > 0 && sky_h > 0);
+    std::vector<std::shared_ptr<Object>> objs;
+    objs.push_back(std::make_shared<Object>(tmesh, mat_lambert(tex_uv())));
+    objs.push_back(std::make_shared<Object>(make_sphere(V3(c[0], c[1] - 2.6f, bb.min[2] + 0.9f), 0.9f), mat_lambert(tex_checkerboard(8))));
+    objs.push_back(std::make_shared<Object>(make_sphere(V3(c[0], c[1] + 2.6f, bb.min[2] + 0.9f), 0.9f),
+                                            mat_glossy(20.0f, 0.4f, have_image ? tex_image(timg) : tex_checkerboard(6))));
+    objs.push_back(std::make_shared<Object>(make_sphere(V3(c[0] - 2.2f, c[1] - 0.6f, bb.min[2] + 0.6f), 0.6f), mat_transparent(1.5f)));  // Glass
+    objs.push_back(std::make_shared<Object>(std::make_shared<Triangle>(V3(c[0] + 1.5f, c[1] - 3.0f, bb.min[2] + 0.01f), V3(c[0] + 1.5f, c[1] + 3.0f, bb.min[2] + 0.01f),
+                                                                       V3(c[0] + 1.5f, c[1], bb.min[2] + 3.0f)),
+                                            mat_lambert(tex_checkerboard(4))));
+    objs.push_back(std::make_shared<Object>(std::make_shared<Cuboid>(V3(-5.0f, -5.0f, bb.min[2]), V3(5.0f, 5.0f, bb.min[2] - 1.0f)),
+                                            mat_glossy(1e3f, 0.3f, tex_checkerboard(10))));
+    auto list = std::make_shared<GeometryList>();
+    for (auto& o : objs) list->items.push_back(o);
+    finalize_object_ids(s, objs);
+    s->cam_pos = V3(-6.0f, -6.0f, 3.0f); s->cam_focus = c + V3(0.0f, 0.0f, 0.1f); s->cam_up = -V3(0.f, 0.f, 1.f);
+    s->make_camera((size_t)cam_w, (size_t)cam_h);
+    s->scene.root = list;
+    s->scene.skybox = sky;
     s->scene.lights = main_lights();
     return s;
 }
@@ -504,6 +548,15 @@ int orc_kat_ply(const char* path, uint32_t counts[2], uint32_t* first_faces, int
 void orc_kat_rotation(const float axis[3], float angle, float out9[9]) {
     Mat3 m = Mat3::new_rotation(V3(axis[0], axis[1], axis[2]), angle);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out9[3 * i + j] = m.m[i][j];
+}
+// Material::sample_at of Lambartian(texture) at (u, v): kind 0 colour (white), 1 UV, 2 checkerboard(param), 3 image (rgb, w x h).
+void orc_kat_texture(int kind, int param, const uint8_t* rgb, int w, int h, float u, float v, float out[3]) {
+    Texture t;
+    if (kind == TEX_UV) t = tex_uv();
+    else if (kind == TEX_CHECKERBOARD) t = tex_checkerboard(param);
+    else if (kind == TEX_IMAGE) t = tex_image(make_sky(rgb, w, h));
+    Color c = mat_lambert(t).sample_at(u, v);
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
 }
 void orc_kat_sky(void* p, const float dir[3], float out[3]) {
     OrcScene* s = (OrcScene*)p;

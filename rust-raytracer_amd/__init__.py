@@ -122,6 +122,8 @@ def host_lib():
         _host.rth_scene_spheres.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_terrain.restype = C.c_void_p
         _host.rth_scene_terrain.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _host.rth_scene_textured.restype = C.c_void_p
+        _host.rth_scene_textured.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_grid.restype = C.c_void_p
         _host.rth_scene_grid.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_free.argtypes = [C.c_void_p]
@@ -190,6 +192,14 @@ class Scene:
         """Heightfield mesh of n x n cells (with coplanar duplicate triangles), optionally with two bunny instances."""
         sky, p, w, h = cls._sky_args(sky)
         return cls(host_lib().rth_scene_terrain(ply.encode(), n, seed, int(with_bunny), p, w, h, cam[0], cam[1]), sky)
+
+    @classmethod
+    def textured(cls, sky=None, tex=None, cam=(1080, 960), ply=BUNNY_PLY):
+        """UV / checkerboard / image textures, Glass and a standalone triangle in one list (tex: RGB8 array for the
+        image-textured sphere; None = the skybox image)."""
+        sky, p, w, h = cls._sky_args(sky)
+        tex, tp, tw, th = cls._sky_args(tex)
+        return cls(host_lib().rth_scene_textured(ply.encode(), p, w, h, tp, tw, th, cam[0], cam[1]), sky)
 
     def __del__(self):
         try:

@@ -454,8 +454,12 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     for (uint32_t k = 0; k < sc->n_materials; k++) {
         const rtamd_material& m = sc->materials[k];
         if (m.kind > RTAMD_MAT_LAMBERT) return fail(ctx, RTAMD_E_INVALID, "unknown material kind");
+        if (m.tex_kind > RTAMD_TEX_IMAGE) return fail(ctx, RTAMD_E_INVALID, "unknown texture kind");
+        if (m.tex_kind == RTAMD_TEX_IMAGE && (m.tex_param < 0 || (uint32_t)m.tex_param >= sc->n_images || !sc->images))
+            return fail(ctx, RTAMD_E_INVALID, "material image index out of bounds");
         DevMaterial d{};
         d.kind = m.kind; d.p0 = m.p0; d.p1 = m.p1; std::memcpy(d.color, m.color, 12);
+        d.tex_kind = m.tex_kind; d.tex_param = m.tex_param;
         materials.push_back(d);
     }
     std::vector<DevLight> lights;
@@ -479,6 +483,18 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         sw = sh = 1;
         sky.assign(1, 0xFF808080u);
     }
+    // image textures: their texels follow the skybox in the same array
+    std::vector<DevImage> images;
+    for (uint32_t k = 0; k < sc->n_images; k++) {
+        const rtamd_image& im = sc->images[k];
+        if (!im.rgb || im.w == 0 || im.h == 0) return fail(ctx, RTAMD_E_INVALID, "empty texture image");
+        const size_t first = sky.size(), n = (size_t)im.w * im.h;
+        if (first + n > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "texture images too large");
+        images.push_back(DevImage{(uint32_t)first, im.w, im.h, 0u});
+        sky.resize(first + n);
+        for (size_t t = 0; t < n; t++)
+            sky[first + t] = (uint32_t)im.rgb[3 * t] | ((uint32_t)im.rgb[3 * t + 1] << 8) | ((uint32_t)im.rgb[3 * t + 2] << 16) | 0xFF000000u;
+    }
 
     DevScene S{};
     if ((rc = upload_vec(ctx, nodes, &S.nodes))) return rc;
@@ -494,6 +510,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     if ((rc = upload_vec(ctx, materials, &S.materials))) return rc;
     if ((rc = upload_vec(ctx, lights, &S.lights))) return rc;
     if ((rc = upload_vec(ctx, sky, &S.sky))) return rc;
+    if ((rc = upload_vec(ctx, images, &S.images))) return rc;
     S.n_root = sc->n_root; S.n_lights = sc->n_lights; S.sky_w = sw; S.sky_h = sh;
     S.n_objects = sc->n_objects; S.n_meshes = sc->n_meshes;
     // LDS staging: the first mesh whose nodes + triangles fit in 52 KiB (three 512-thread blocks per CU)

@@ -45,7 +45,9 @@ struct DevObject {
 };
 enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8 };
 struct DevRootItem { uint32_t kind, index; };
-struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t pad[2]; };
+struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t tex_kind; int32_t tex_param; };
+struct DevImage { uint32_t first, w, h, pad; };   // texels at sky[first ...], row-major
+enum { TEX_COLOR = 0, TEX_UV = 1, TEX_CHECKERBOARD = 2, TEX_IMAGE = 3 };
 struct DevLight { uint32_t kind; float vec[3]; float param; float emission[3]; };
 
 enum { OP_TRANSLATE = 0, OP_SCALE = 1, OP_ROTATE = 2 };
@@ -67,7 +69,8 @@ struct DevScene {
     const DevRootItem* root;
     const DevMaterial* materials;
     const DevLight* lights;
-    const uint32_t* sky;  // RGBA8, one word per texel
+    const uint32_t* sky;  // RGBA8, one word per texel; the texels of the image textures follow the skybox
+    const DevImage* images;
     uint32_t n_root, n_lights, sky_w, sky_h;
     uint32_t n_objects, n_meshes;
     uint32_t root_first;      // root list = plain objects root_first, root_first + 1, ...: that first index; else MISS

@@ -209,15 +209,38 @@ static constexpr float PI_F = 3.14159274101257324219f;
 __device__ __forceinline__ float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
 __device__ __forceinline__ float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
 
-__device__ __forceinline__ f3 sky_color(const DevScene& S, f3 d) {
-    float u = atan2f(d.x, d.y) / PI_F * 0.5f + 0.5f;
-    float v = acosf(d.z) / PI_F;
-    float fw = (float)S.sky_w, fh = (float)S.sky_h;
+// Image::color_at, src/texture.rs:70-82: nearest texel, clamped.
+__device__ __forceinline__ f3 image_texel(const DevScene& S, uint32_t first, uint32_t w, uint32_t h, float u, float v) {
+    float fw = (float)w, fh = (float)h;
     float fx = rust_max(rust_min(u * fw, fw - 1.0f), 0.0f);
     float fy = rust_max(rust_min(v * fh, fh - 1.0f), 0.0f);
     uint32_t x = (uint32_t)fx, y = (uint32_t)fy;
-    uint32_t p = S.sky[(size_t)y * S.sky_w + x];
+    uint32_t p = S.sky[first + (size_t)y * w + x];
     return mk((float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f, (float)((p >> 16) & 0xFFu) / 255.0f);
+}
+__device__ __forceinline__ f3 sky_color(const DevScene& S, f3 d) {   // scene.rs:16-21
+    float u = atan2f(d.x, d.y) / PI_F * 0.5f + 0.5f;
+    float v = acosf(d.z) / PI_F;
+    return image_texel(S, 0u, S.sky_w, S.sky_h, u, v);
+}
+__device__ __forceinline__ int32_t sat_i32(float x) {  // `as i32`: saturating, NaN -> 0
+    if (!(x == x)) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int32_t)x;
+}
+__device__ __forceinline__ f3 texture_color(const DevScene& S, const DevMaterial& m, float u, float v) {
+    if (m.tex_kind == TEX_UV) return mk(u, v, 0.0f);                 // texture.rs:22-26
+    if (m.tex_kind == TEX_CHECKERBOARD) {                             // texture.rs:36-47
+        const int32_t i = sat_i32(u * (float)m.tex_param);
+        const int32_t j = sat_i32(v * (float)m.tex_param);
+        return ((i % 2 == 0) != (j % 2 == 0)) ? mk(0.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
+    }
+    if (m.tex_kind == TEX_IMAGE) {
+        const DevImage im = S.images[m.tex_param];
+        return image_texel(S, im.first, im.w, im.h, u, v);
+    }
+    return mk(m.color[0], m.color[1], m.color[2]);                    // texture.rs:14-18
 }
 
 __device__ __forceinline__ f3 reflection(f3 n, f3 i) { return i - (2.0f * n) * dot(n, i); }  // material.rs:83-85
@@ -248,10 +271,10 @@ __device__ __forceinline__ float fresnel(f3 normal, f3 i, float ior) {          
     }
     return 1.0f;
 }
-__device__ __forceinline__ f3 material_diffuse(const DevMaterial& m) {  // Material::sample_at
+__device__ __forceinline__ f3 material_diffuse(const DevScene& S, const DevMaterial& m, float u, float v) {  // Material::sample_at
     if (m.kind == MAT_NULL) return mk(0.f, 1.f, 0.f);
-    if (m.kind == MAT_LAMBERT) return mk(m.color[0], m.color[1], m.color[2]);
-    if (m.kind == MAT_GLOSSY) return mk(m.color[0], m.color[1], m.color[2]) * (1.0f - m.p1);
+    if (m.kind == MAT_LAMBERT) return texture_color(S, m, u, v);
+    if (m.kind == MAT_GLOSSY) return texture_color(S, m, u, v) * (1.0f - m.p1);
     return mk(0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ bool material_scatter(const DevMaterial& m, f3 n, f3 i, Rng& rng, f3& out_dir, f3& w) {
@@ -637,7 +660,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
                 p_out = hp + nrm * 0.001f;
                 p_in = hp - nrm * 0.001f;
                 p = outside ? p_out : p_in;
-                diffuse = material_diffuse(S.materials[mat]);
+                diffuse = material_diffuse(S, S.materials[mat], hu, hv);
                 lit = !is_zero(diffuse);                               // integrator.rs:80
             }
         }
@@ -855,7 +878,7 @@ __global__ __launch_bounds__(256) void k_pixel_depth_first(DevScene S, RegionDev
                                 cur.color = fill(0.0f);
                                 cur.k = 0;
                                 const f3 p = outside ? cur.p_out : cur.p_in;
-                                const f3 diffuse = material_diffuse(S.materials[cur.mat]);
+                                const f3 diffuse = material_diffuse(S, S.materials[cur.mat], hu, hv);
                                 if (!is_zero(diffuse)) {
                                     f3 illum = fill(0.0f);
                                     for (uint32_t l = 0; l < S.n_lights; l++) {   // illumination(), integrator.rs:107-132

@@ -79,17 +79,20 @@ Vec3D Mat3D::transpose_apply(Vec3D a) const {
 }
 
 // ---- materials / lights ----------------------------------------------------------------------------
-static Material mk_mat(uint32_t kind, float p0, float p1, Color c) {
+static Material mk_mat(uint32_t kind, float p0, float p1, const Texture& t) {
     Material m;
     m.m.kind = kind; m.m.p0 = p0; m.m.p1 = p1;
-    m.m.color[0] = c.x; m.m.color[1] = c.y; m.m.color[2] = c.z;
+    m.m.color[0] = t.color.x; m.m.color[1] = t.color.y; m.m.color[2] = t.color.z;
+    m.m.tex_kind = t.kind; m.m.tex_param = t.param;   // image textures: the index is assigned when the scene is flattened
+    m.image = t.image;
+    if (t.kind == RTAMD_TEX_IMAGE && !t.image) throw std::runtime_error("image texture without an image");
     return m;
 }
-Material NullMaterial() { return mk_mat(RTAMD_MAT_NULL, 0.f, 0.f, COLOR_WHITE); }
-Material Metal() { return mk_mat(RTAMD_MAT_METAL, 0.f, 0.f, COLOR_WHITE); }
-Material Glossy(float e, float k, Color c) { return mk_mat(RTAMD_MAT_GLOSSY, e, k, c); }
-Material Transparent(float ior) { return mk_mat(RTAMD_MAT_TRANSPARENT, ior, 0.f, COLOR_WHITE); }
-Material Lambartian(Color c) { return mk_mat(RTAMD_MAT_LAMBERT, 0.f, 0.f, c); }
+Material NullMaterial() { return mk_mat(RTAMD_MAT_NULL, 0.f, 0.f, Texture(COLOR_WHITE)); }
+Material Metal() { return mk_mat(RTAMD_MAT_METAL, 0.f, 0.f, Texture(COLOR_WHITE)); }
+Material Glossy(float e, float k, Texture t) { return mk_mat(RTAMD_MAT_GLOSSY, e, k, t); }
+Material Transparent(float ior) { return mk_mat(RTAMD_MAT_TRANSPARENT, ior, 0.f, Texture(COLOR_WHITE)); }
+Material Lambartian(Texture t) { return mk_mat(RTAMD_MAT_LAMBERT, 0.f, 0.f, t); }
 
 static Light mk_light(uint32_t kind, Vec3D v, float param, Color emission) {
     Light l;
@@ -269,6 +272,13 @@ void bvh_statistics(const BvhTree& t, uint32_t out[5]) {
 }
 
 // ---- geometry ----------------------------------------------------------------------------------------
+uint32_t FlatScene::image_index(const std::shared_ptr<const Image>& img) {
+    for (size_t k = 0; k < image_refs.size(); k++)
+        if (image_refs[k].get() == img.get()) return (uint32_t)k;
+    image_refs.push_back(img);
+    images.push_back(rtamd_image{img->rgb.data(), img->width, img->height});
+    return (uint32_t)(images.size() - 1);
+}
 uint32_t FlatScene::mesh_index(const std::shared_ptr<const Mesh>& m) {
     for (size_t k = 0; k < mesh_refs.size(); k++)
         if (mesh_refs[k].get() == m.get()) return (uint32_t)k;
@@ -487,7 +497,12 @@ void Device::check(int rc, const char* what) const {
 
 void Scene::upload(Device& dev) {
     auto fs = std::make_shared<FlatScene>();
-    auto add_material = [&](const Material& m) { fs->materials.push_back(m.m); return (uint32_t)fs->materials.size() - 1; };
+    auto add_material = [&](const Material& m) {
+        rtamd_material flat = m.m;
+        if (flat.tex_kind == RTAMD_TEX_IMAGE) flat.tex_param = (int32_t)fs->image_index(m.image);
+        fs->materials.push_back(flat);
+        return (uint32_t)fs->materials.size() - 1;
+    };
     std::vector<rtamd_xform_op> ops;
     for (const auto& it : root.items) {
         if (it.is_tree) {
@@ -522,6 +537,7 @@ void Scene::upload(Device& dev) {
     d.materials = fs->materials.data(); d.n_materials = (uint32_t)fs->materials.size();
     d.lights = fs->lights.data(); d.n_lights = (uint32_t)fs->lights.size();
     if (skybox) { d.skybox_rgb = skybox->rgb.data(); d.sky_w = skybox->width; d.sky_h = skybox->height; }
+    d.images = fs->images.data(); d.n_images = (uint32_t)fs->images.size();
     dev.check(rtamd_upload_scene(dev.ctx, &d), "rtamd_upload_scene");
     flat_ = fs;
 }

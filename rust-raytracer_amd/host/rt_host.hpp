@@ -74,13 +74,26 @@ typedef Vec3D Color;
 static const Color COLOR_WHITE(1.f, 1.f, 1.f);
 static const Color COLOR_BLACK(0.f, 0.f, 0.f);
 
-struct Material { rtamd_material m; };
+struct Image;
+struct Texture {  // trait Texture and its impls, texture.rs:10-47, :70-82
+    uint32_t kind = RTAMD_TEX_COLOR;
+    Color color = Color(1.f, 1.f, 1.f);
+    int32_t param = 0;
+    std::shared_ptr<const Image> image;
+    Texture() {}
+    Texture(Color c) : color(c) {}                               // impl Texture for Color
+    Texture(std::shared_ptr<const Image> img) : kind(RTAMD_TEX_IMAGE), image(img) {}   // impl Texture for Image
+};
+inline Texture UVTexture() { Texture t; t.kind = RTAMD_TEX_UV; return t; }
+inline Texture Checkerboard(int repeats) { Texture t; t.kind = RTAMD_TEX_CHECKERBOARD; t.param = repeats; return t; }
+
+struct Material { rtamd_material m; std::shared_ptr<const Image> image; };
 Material NullMaterial();
 Material Metal();
-Material Glossy(float exponent, float mirror, Color c);
+Material Glossy(float exponent, float mirror, Texture t);
 Material Transparent(float ior);
 inline Material Glass() { return Transparent(1.5f); }   // material.rs:72-78
-Material Lambartian(Color c);                            // [sic], material.rs:135
+Material Lambartian(Texture t);                          // [sic], material.rs:135
 
 struct Light { rtamd_light l; };
 Light AmbientLight(Color color, float intensity);
@@ -108,7 +121,10 @@ struct FlatScene {  // owns every array rtamd_scene_desc points to
     std::vector<rtamd_root_item> root;
     std::vector<rtamd_material> materials;
     std::vector<rtamd_light> lights;
+    std::vector<std::shared_ptr<const Image>> image_refs;
+    std::vector<rtamd_image> images;
     uint32_t mesh_index(const std::shared_ptr<const Mesh>& m);
+    uint32_t image_index(const std::shared_ptr<const Image>& img);
 };
 
 // ---- geometry (src/geom/*.rs) ---------------------------------------------------------------------
@@ -289,5 +305,6 @@ Scene scene_main(const std::string& ply_path, std::shared_ptr<const Image> skybo
 Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 Scene scene_terrain(const std::string& ply_path, int n, uint64_t seed, bool with_bunny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
+Scene scene_textured(const std::string& ply_path, std::shared_ptr<const Image> skybox, std::shared_ptr<const Image> tex, size_t cam_w, size_t cam_h);
 
 }  // namespace rth

@@ -46,6 +46,16 @@ void* rth_scene_grid(const char* ply, int nx, int ny, const uint8_t* sky, int sw
 void* rth_scene_terrain(const char* ply, int n, uint64_t seed, int with_bunny, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_terrain(ply, n, seed, with_bunny != 0, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
 }
+// tex = NULL: the textured sphere takes the skybox image
+void* rth_scene_textured(const char* ply, const uint8_t* sky, int sw, int sh, const uint8_t* tex, int tw, int th, int cam_w, int cam_h) {
+    return guarded([&]() -> void* {
+        auto* h = new Handle();
+        std::shared_ptr<const Image> timg;
+        if (tex && tw > 0 && th > 0) timg = Image::from_rgb(tex, (uint32_t)tw, (uint32_t)th);
+        h->scene = scene_textured(ply, sky_from(sky, sw, sh), timg, (size_t)cam_w, (size_t)cam_h);
+        return h;
+    });
+}
 void rth_scene_free(void* p) { delete (Handle*)p; }
 
 // Camera::new(w, h).position(pos).look_towards(dir, up) at another resolution, keeping the pose:

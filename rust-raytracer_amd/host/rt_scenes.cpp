@@ -150,4 +150,31 @@ Scene scene_terrain(const std::string& ply_path, int n, uint64_t seed, bool with
     return scene;
 }
 
+// Every texture and the materials main.rs does not use, in a plain GeometryList: the scaled + rotated mesh with a
+// UV texture (barycentric u, v), a checkerboard sphere, a glossy sphere textured with `tex` (the skybox image when the
+// caller has none), a Glass sphere, a standalone triangle with a coarse checkerboard and a checkerboard floor.
+Scene scene_textured(const std::string& ply_path, std::shared_ptr<const Image> skybox, std::shared_ptr<const Image> tex, size_t cam_w, size_t cam_h) {
+    std::vector<Object> list;
+    auto mesh = loader::load_ply_as_mesh(ply_path);
+    GeomPtr tmesh = Transform::make(mesh)->scale(20.0f)->rotate_x(to_radians(90.0f));
+    AABB bb = tmesh->bounding_box();
+    Vec3D c = (bb.min + bb.max) / 2.0f;
+    list.push_back(Object::with_material(tmesh, Lambartian(UVTexture())));
+    list.push_back(Object::with_material(Sphere(Vec3D(c.x, c.y - 2.6f, bb.min.z + 0.9f), 0.9f), Lambartian(Checkerboard(8))));
+    list.push_back(Object::with_material(Sphere(Vec3D(c.x, c.y + 2.6f, bb.min.z + 0.9f), 0.9f), Glossy(20.0f, 0.4f, (tex || skybox) ? Texture(tex ? tex : skybox) : Checkerboard(6))));
+    list.push_back(Object::with_material(Sphere(Vec3D(c.x - 2.2f, c.y - 0.6f, bb.min.z + 0.6f), 0.6f), Glass()));
+    list.push_back(Object::with_material(std::make_shared<Triangle>(Vec3D(c.x + 1.5f, c.y - 3.0f, bb.min.z + 0.01f), Vec3D(c.x + 1.5f, c.y + 3.0f, bb.min.z + 0.01f),
+                                                                    Vec3D(c.x + 1.5f, c.y, bb.min.z + 3.0f)),
+                                         Lambartian(Checkerboard(4))));
+    list.push_back(Object::with_material(Cuboid::make(vec3d(-5.0f, -5.0f, bb.min.z), vec3d(5.0f, 5.0f, bb.min.z - 1.0f)), Glossy(1e3f, 0.3f, Checkerboard(10))));
+    Scene scene;
+    for (auto& o : list) scene.root.push(o);
+    Camera cam(cam_w, cam_h);
+    cam.position(Vec3D(-6.0f, -6.0f, 3.0f)).look_at(c + Vec3D(0.0f, 0.0f, 0.1f), -Vec3D::z_axis());
+    scene.camera = cam;
+    scene.skybox = skybox;
+    scene.lights = main_lights();
+    return scene;
+}
+
 }  // namespace rth

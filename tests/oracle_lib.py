@@ -42,6 +42,8 @@ def lib():
         _lib.orc_scene_main.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_spheres.restype = C.c_void_p
         _lib.orc_scene_spheres.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.orc_scene_textured.restype = C.c_void_p
+        _lib.orc_scene_textured.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_terrain.restype = C.c_void_p
         _lib.orc_scene_terrain.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_grid.restype = C.c_void_p
@@ -119,6 +121,16 @@ class OracleScene:
     def terrain(cls, n, seed=1, with_bunny=True, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
         sky = procedural_sky() if sky is None else np.ascontiguousarray(sky, dtype=np.uint8)
         hnd = lib().orc_scene_terrain(ply.encode(), n, seed, int(with_bunny), sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
+        return cls(hnd, sky)
+
+    @classmethod
+    def textured(cls, sky=None, tex=None, cam=(1080, 960), ply=BUNNY_PLY):
+        sky = procedural_sky() if sky is None else np.ascontiguousarray(sky, dtype=np.uint8)
+        if tex is None:
+            hnd = lib().orc_scene_textured(ply.encode(), sky.ctypes.data, sky.shape[1], sky.shape[0], None, 0, 0, cam[0], cam[1])
+        else:
+            tex = np.ascontiguousarray(tex, dtype=np.uint8)
+            hnd = lib().orc_scene_textured(ply.encode(), sky.ctypes.data, sky.shape[1], sky.shape[0], tex.ctypes.data, tex.shape[1], tex.shape[0], cam[0], cam[1])
         return cls(hnd, sky)
 
     def __del__(self):
@@ -272,3 +284,15 @@ def kat_rotation(axis, angle):
     lib().orc_kat_rotation.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
     lib().orc_kat_rotation(_f3(axis), angle, out.ctypes.data)
     return out.reshape(3, 3)
+
+
+def kat_texture(kind, u, v, param=0, image=None):
+    """Lambartian(texture).sample_at(u, v); kind 0 colour, 1 UV, 2 checkerboard(param), 3 image (H x W x 3 uint8)."""
+    out = np.zeros(3, np.float32)
+    lib().orc_kat_texture.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    if image is None:
+        lib().orc_kat_texture(kind, param, None, 0, 0, u, v, out.ctypes.data)
+    else:
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        lib().orc_kat_texture(kind, param, image.ctypes.data, image.shape[1], image.shape[0], u, v, out.ctypes.data)
+    return out

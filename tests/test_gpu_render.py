@@ -9,6 +9,8 @@ of the pixel components off by more than 1e-3; in practice almost every pixel ag
 import numpy as np
 import pytest
 
+from test_gpu_trace import check_closest
+
 pytestmark = pytest.mark.gpu
 
 RMSE_TOL = 2e-3
@@ -126,6 +128,22 @@ def test_terrain_scene_with_point_lights_renders(rt, ol, sky):
         ref, _, cnt = cpu.render(**params)
         compare(img, ref)
         assert abs(st["any_rays"] - cnt["any_rays"]) <= 2e-3 * max(1, cnt["any_rays"])
+
+
+def test_textured_scene_renders(rt, ol, sky):
+    """UVTexture, Checkerboard and Image textures on Lambartian / Glossy, Glass and a standalone Triangle; both integrator forms."""
+    cam = (200, 160)
+    tex = (np.arange(37 * 53 * 3) * 7 % 256).astype(np.uint8).reshape(37, 53, 3)
+    for t in (tex, None):
+        gpu, cpu = rt.Scene.textured(sky=sky, tex=t, cam=cam).upload(0), ol.OracleScene.textured(sky=sky, tex=t, cam=cam)
+        rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+        c = cpu.trace_closest(rays)
+        check_closest(rt, gpu.trace_closest(rays), c, exact_uv=False)   # spheres: u, v through atan2 / acos
+        assert set(np.unique(c["obj"])) >= {0, 1, 2, 3, 4, 5}   # every object is in view
+        for params in (dict(max_depth=4, shadow_rays=1, antialiasing=2), dict(max_depth=3, shadow_rays=1, scatter_rays=2, antialiasing=1)):
+            img, _ = gpu.render(**params)
+            ref, _, _ = cpu.render(**params)
+            compare(img, ref)
 
 
 def test_tuning_options_do_not_change_pixels(rt, sky):

@@ -60,6 +60,19 @@ def test_terrain_scene_host_matches_oracle(rt, ol, sky):
         assert gs[0] == 2 * n * n + sum(1 for iy in range(n) for ix in range(n) if (ix + iy) % 7 == 0)  # duplicates are kept
 
 
+def test_textured_scene_host_matches_oracle(rt, ol, sky):
+    """Same mesh tree and camera on both sides of the textured scene (materials are compared through the GPU render)."""
+    tex = (np.arange(5 * 7 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
+    g, c = rt.Scene.textured(sky=sky, tex=tex, cam=(64, 48)), ol.OracleScene.textured(sky=sky, tex=tex, cam=(64, 48))
+    gn, go, gs = g.tree(0)
+    cn, co, cs = c.bvh(0)
+    assert np.array_equal(gn, cn) and np.array_equal(go, co) and np.array_equal(gs, cs)
+    gc = g.camera()
+    cc, wh = c.camera()
+    flat = np.array(list(gc.pos) + list(gc.dir) + list(gc.horizontal) + list(gc.vertical), np.float32)
+    assert np.array_equal(flat.view(np.uint32), cc.view(np.uint32)) and (gc.width, gc.height) == wh
+
+
 def test_no_cpu_fallback(rt, sky):
     """Without an uploaded GPU context every trace / render call must raise, never compute on the host."""
     s = rt.Scene.main(sky=sky, cam=(32, 32))

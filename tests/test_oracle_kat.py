@@ -183,3 +183,28 @@ def test_render_is_deterministic_and_tile_invariant(ol, sky):
     assert np.array_equal(full.view(np.uint32), again.view(np.uint32))
     part, _, _ = s.render(max_depth=4, antialiasing=2, rect=(30, 20, 40, 30), threads=3)
     assert np.array_equal(part.view(np.uint32), full[20:50, 30:70].view(np.uint32))
+
+
+def test_textures(ol):
+    """texture.rs:14-47,70-82 by hand: UV, checkerboard parity with truncating casts, nearest-texel image lookup."""
+    nan = float("nan")
+    assert np.array_equal(ol.kat_texture(0, 0.3, 0.9), [1, 1, 1])
+    assert np.array_equal(ol.kat_texture(1, 0.25, 0.75), np.array([0.25, 0.75, 0.0], np.float32))
+    black, white = [0, 0, 0], [1, 1, 1]
+    # Checkerboard(8): i = (u * 8) as i32, j likewise; black where exactly one of them is even
+    assert np.array_equal(ol.kat_texture(2, 0.1, 0.2, param=8), black)     # i = 0, j = 1
+    assert np.array_equal(ol.kat_texture(2, 0.1, 0.3, param=8), white)     # i = 0, j = 2
+    assert np.array_equal(ol.kat_texture(2, 0.2, 0.2, param=8), white)     # i = 1, j = 1
+    assert np.array_equal(ol.kat_texture(2, -0.3, 0.0, param=8), white)    # i = -2 (truncation towards zero), j = 0
+    assert np.array_equal(ol.kat_texture(2, -0.2, 0.0, param=8), black)    # i = -1: -1 % 2 = -1, odd
+    assert np.array_equal(ol.kat_texture(2, -0.05, 0.0, param=8), white)   # i = 0 (-0.4 truncates to 0)
+    assert np.array_equal(ol.kat_texture(2, nan, 0.2, param=8), black)     # NaN as i32 = 0
+    assert np.array_equal(ol.kat_texture(2, 1e30, 0.0, param=8), black)    # saturates to i32::MAX (odd), j = 0
+    # Image 3 x 2 (w x h): x = clamp(u * w, 0, w - 1) as u32
+    img = np.arange(18, dtype=np.uint8).reshape(2, 3, 3) * 10
+    px = lambda x, y: img[y, x].astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(ol.kat_texture(3, 0.5, 0.2, image=img), px(1, 0))   # u * 3 = 1.5 -> 1; v * 2 = 0.4 -> 0
+    assert np.array_equal(ol.kat_texture(3, 0.99, 0.99, image=img), px(2, 1))
+    assert np.array_equal(ol.kat_texture(3, 1.5, 7.0, image=img), px(2, 1))   # clamped to w - 1, h - 1
+    assert np.array_equal(ol.kat_texture(3, -1.0, -0.1, image=img), px(0, 0))
+    assert np.array_equal(ol.kat_texture(3, nan, 0.0, image=img), px(2, 0))   # NaN.min(w - 1) = w - 1
