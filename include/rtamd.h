@@ -77,8 +77,11 @@ typedef struct rtamd_triangle {
  * src/geom/transform.rs:5-22.
  *   TRANSLATE: v[0..2] = offset            (transform.rs:55-72)
  *   SCALE:     v[0] = scale, v[1] = inv    (transform.rs:100-120)
- *   ROTATE:    v[0..8] = row-major 3x3     (transform.rs:175-198) */
-enum rtamd_op_kind { RTAMD_OP_TRANSLATE = 0, RTAMD_OP_SCALE = 1, RTAMD_OP_ROTATE = 2 };
+ *   ROTATE:    v[0..8] = row-major 3x3     (transform.rs:175-198)
+ *   BOUNDS:    v[0..2] = min, v[3..5] = max of the padded box of a BoundingBox<T> (aggregate.rs:59-96):
+ *              the wrapped object is only tried by rays whose slab interval (t_in, t_out) of the box
+ *              exists with t_in <= t_max and t_out >= 0 */
+enum rtamd_op_kind { RTAMD_OP_TRANSLATE = 0, RTAMD_OP_SCALE = 1, RTAMD_OP_ROTATE = 2, RTAMD_OP_BOUNDS = 3 };
 typedef struct rtamd_xform_op {
     uint32_t kind;
     float v[9];

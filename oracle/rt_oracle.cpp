@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -35,6 +36,14 @@ bool AABB::fast_intersect_ray(V3 ray_pos, V3 inv_dir, const bool neg[3], float& 
     }
     t0 = max3(a[0], a[1], a[2]);
     t1 = min3(b[0], b[1], b[2]);
+    return t0 < t1;
+}
+
+bool AABB::intersect_ray(V3 ray_pos, V3 inv_dir, float& t0, float& t1) const {  // aabb.rs:47-59
+    V3 a = (min - ray_pos) * inv_dir;
+    V3 b = (max - ray_pos) * inv_dir;
+    t0 = max3(min2(a[0], b[0]), min2(a[1], b[1]), min2(a[2], b[2]));
+    t1 = min3(max2(a[0], b[0]), max2(a[1], b[1]), max2(a[2], b[2]));
     return t0 < t1;
 }
 
@@ -375,6 +384,28 @@ bool MeshTriangle::hit(const Ray& ray, float t_max, HitResult& h) const {  // me
         return true;
     }
     return false;
+}
+std::shared_ptr<Mesh> Mesh::from_triangles(const std::vector<std::array<V3, 3>>& tris) {  // mesh.rs:83-116
+    std::vector<V3> vertices;
+    std::vector<std::array<uint32_t, 3>> faces;
+    // the reference keys a HashMap by the 12 bytes of the vertex; ids are handed out in order of first appearance,
+    // so the container's iteration order plays no part
+    std::vector<std::array<uint32_t, 3>> keys;
+    for (const auto& tri : tris) {
+        std::array<uint32_t, 3> face{};
+        for (int i = 0; i < 3; i++) {
+            std::array<uint32_t, 3> key;
+            const float v[3] = {tri[i][0], tri[i][1], tri[i][2]};
+            std::memcpy(key.data(), v, 12);
+            uint32_t index = (uint32_t)keys.size();
+            for (uint32_t k = 0; k < keys.size(); k++)
+                if (keys[k] == key) { index = k; break; }
+            if (index == keys.size()) { keys.push_back(key); vertices.push_back(tri[i]); }
+            face[i] = index;
+        }
+        faces.push_back(face);
+    }
+    return from_vertices(vertices, faces);
 }
 std::shared_ptr<Mesh> Mesh::from_vertices(const std::vector<V3>& vertices,
                                           const std::vector<std::array<uint32_t, 3>>& faces) {
@@ -783,6 +814,26 @@ AABB GeometryList::bounding_box() const {  // :47-55
     AABB b;
     for (const auto& g : items) b = b.union_(g->bounding_box());
     return b;
+}
+BoundingBox::BoundingBox(GeomPtr o) : obj(o) {  // aggregate.rs:62-69
+    AABB bbox = o->bounding_box();
+    V3 delta = bbox.max - bbox.min;
+    V3 pad = V3::fill(delta[0] + delta[1] * delta[2]) * 0.001f;
+    box = AABB::from_points(bbox.min - pad, bbox.max + pad);
+}
+bool BoundingBox::hit(const Ray& ray, float t_max, HitResult& h) const {  // aggregate.rs:73-81
+    float t_in, t_out;
+    if (box.intersect_ray(ray.pos, ray.inv_dir, t_in, t_out)) {
+        if (t_in <= t_max && t_out >= 0.0f) return obj->hit(ray, t_max, h);
+    }
+    return false;
+}
+bool BoundingBox::is_hit(const Ray& ray, float t_max) const {  // aggregate.rs:83-91
+    float t_in, t_out;
+    if (box.intersect_ray(ray.pos, ray.inv_dir, t_in, t_out)) {
+        if (t_in <= t_max && t_out >= 0.0f) return obj->is_hit(ray, t_max);
+    }
+    return false;
 }
 bool GeometryList::hit(const Ray& ray, float t_max, HitResult& result) const {  // :24-35
     bool found = false;

@@ -104,6 +104,8 @@ struct AABB {
     }
     // aabb.rs:61-87
     bool fast_intersect_ray(V3 ray_pos, V3 inv_dir, const bool neg[3], float& t0, float& t1) const;
+    // aabb.rs:47-59
+    bool intersect_ray(V3 ray_pos, V3 inv_dir, float& t0, float& t1) const;
 };
 
 // ---------------------------------------------------------------- math/mat3d.rs
@@ -244,6 +246,7 @@ struct Mesh : Geometry {  // mesh.rs:16-81
     std::shared_ptr<const MeshData> data;
     static std::shared_ptr<Mesh> from_vertices(const std::vector<V3>& vertices,
                                                const std::vector<std::array<uint32_t, 3>>& faces);
+    static std::shared_ptr<Mesh> from_triangles(const std::vector<std::array<V3, 3>>& tris);  // mesh.rs:83-116
     AABB bounding_box() const override { return tree->bounding_box(); }
     bool hit(const Ray& r, float t, HitResult& h) const override { return tree->hit(r, t, h); }
     bool is_hit(const Ray& r, float t) const override { return tree->is_hit(r, t); }
@@ -316,6 +319,14 @@ struct Object : Geometry {
     AABB bounding_box() const override { return geometry->bounding_box(); }
     bool hit(const Ray& ray, float t_max, HitResult& h) const override;
     bool is_hit(const Ray& ray, float t_max) const override { return geometry->is_hit(ray, t_max); }
+};
+// aggregate.rs:58-96
+struct BoundingBox : Geometry {
+    GeomPtr obj; AABB box;
+    explicit BoundingBox(GeomPtr o);
+    AABB bounding_box() const override { return box; }
+    bool hit(const Ray& ray, float t_max, HitResult& h) const override;
+    bool is_hit(const Ray& ray, float t_max) const override;
 };
 // aggregate.rs:23-56
 struct GeometryList : Geometry {

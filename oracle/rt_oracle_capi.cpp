@@ -17,6 +17,7 @@ struct OrcScene {
     Scene scene;
     WhittedIntegrator integ;
     std::shared_ptr<Mesh> mesh;                        // the (single) shared mesh, if any
+    std::shared_ptr<Mesh> mesh2;                       // a second mesh some synthetic scenes hold
     std::shared_ptr<AABBTree<Object>> object_tree;     // object tree, if any
     std::vector<const Object*> objects;                // flattened object order (global ids)
     V3 cam_pos, cam_focus, cam_up;                     // camera script arguments (main.rs:58-63)
@@ -182,6 +183,19 @@ void* orc_scene_textured(const char* ply_path, const uint8_t* sky_rgb, int sky_w
                                             mat_lambert(tex_checkerboard(4))));
     objs.push_back(std::make_shared<Object>(std::make_shared<Cuboid>(V3(-5.0f, -5.0f, bb.min[2]), V3(5.0f, 5.0f, bb.min[2] - 1.0f)),
                                             mat_glossy(1e3f, 0.3f, tex_checkerboard(10))));
+    // a BoundingBox prefilter around a translated sphere, and one around a flat (zero-thickness in z) triangle, whose
+    // padded box is still flat in z only if dx + dy * dz is 0: here it is not, the triangle stays visible
+    objs.push_back(std::make_shared<Object>(std::make_shared<BoundingBox>(make_sphere(V3(c[0] - 1.0f, c[1] + 3.6f, bb.min[2] + 0.5f), 0.5f)), mat_metal()));
+    objs.push_back(std::make_shared<Object>(std::make_shared<Translate>(
+                                                std::make_shared<BoundingBox>(std::make_shared<Triangle>(V3(0.f, 0.f, 0.f), V3(1.2f, 0.f, 0.f), V3(0.f, 1.2f, 0.f))),
+                                                V3(c[0] - 3.0f, c[1] - 3.0f, bb.min[2] + 0.02f)),
+                                            mat_lambert(tex_uv())));
+    {   // Mesh::from_triangles: a tetrahedron given as four independent triangles (4 shared vertices)
+        V3 p0(0.f, 0.f, 0.f), p1(1.f, 0.f, 0.f), p2(0.f, 1.f, 0.f), p3(0.3f, 0.3f, 1.1f);
+        std::vector<std::array<V3, 3>> tris = {{p0, p2, p1}, {p0, p1, p3}, {p1, p2, p3}, {p2, p0, p3}};
+        s->mesh2 = Mesh::from_triangles(tris);
+        objs.push_back(std::make_shared<Object>(std::make_shared<Translate>(s->mesh2, V3(c[0] - 2.8f, c[1] + 1.6f, bb.min[2])), mat_lambert(tex_checkerboard(3))));
+    }
     auto list = std::make_shared<GeometryList>();
     for (auto& o : objs) list->items.push_back(o);
     finalize_object_ids(s, objs);

@@ -423,7 +423,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     }
     std::vector<DevOp> ops;
     for (uint32_t k = 0; k < sc->n_ops; k++) {
-        if (sc->ops[k].kind > RTAMD_OP_ROTATE) return fail(ctx, RTAMD_E_INVALID, "unknown transform op");
+        if (sc->ops[k].kind > RTAMD_OP_BOUNDS) return fail(ctx, RTAMD_E_INVALID, "unknown transform op");
         DevOp d{};
         d.kind = sc->ops[k].kind;
         std::memcpy(d.v, sc->ops[k].v, sizeof(d.v));

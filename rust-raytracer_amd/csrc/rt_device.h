@@ -50,7 +50,7 @@ struct DevImage { uint32_t first, w, h, pad; };   // texels at sky[first ...], r
 enum { TEX_COLOR = 0, TEX_UV = 1, TEX_CHECKERBOARD = 2, TEX_IMAGE = 3 };
 struct DevLight { uint32_t kind; float vec[3]; float param; float emission[3]; };
 
-enum { OP_TRANSLATE = 0, OP_SCALE = 1, OP_ROTATE = 2 };
+enum { OP_TRANSLATE = 0, OP_SCALE = 1, OP_ROTATE = 2, OP_BOUNDS = 3 };
 enum { GEOM_MESH = 0, GEOM_UNIT_SPHERE = 1, GEOM_CUBOID = 2, GEOM_UNIT_CUBOID = 3, GEOM_TRIANGLE = 4 };
 enum { ROOT_OBJECT = 0, ROOT_TREE = 1 };
 enum { MAT_NULL = 0, MAT_METAL = 1, MAT_GLOSSY = 2, MAT_TRANSPARENT = 3, MAT_LAMBERT = 4 };
@@ -328,8 +328,9 @@ struct LdsTab {
 // ------------------------------------------------------------------------------------------------
 // Ray-space wrappers going in (src/geom/transform.rs:57-58,104-106,178-180).
 // ------------------------------------------------------------------------------------------------
+// Returns false when a BoundingBox wrapper of the chain turns the ray away (aggregate.rs:75-94).
 template <class Tab>
-__device__ __forceinline__ void ops_in(const Tab& tab, uint32_t first, uint32_t count, f3& pos, f3& dir, float& t_max) {
+__device__ __forceinline__ bool ops_in(const Tab& tab, uint32_t first, uint32_t count, f3& pos, f3& dir, float& t_max) {
     for (uint32_t k = 0; k < count; k++) {
         const OpRec op = tab.op(first + k);
         if (op.kind == OP_TRANSLATE) {
@@ -337,11 +338,16 @@ __device__ __forceinline__ void ops_in(const Tab& tab, uint32_t first, uint32_t 
         } else if (op.kind == OP_SCALE) {
             pos = pos * op.v[1];
             t_max = t_max * op.v[1];
-        } else {
+        } else if (op.kind == OP_ROTATE) {
             pos = mat_transpose_apply(op.v, pos);
             dir = mat_transpose_apply(op.v, dir);
+        } else {  // OP_BOUNDS: AABB::intersect_ray with the ray of this space (aabb.rs:47-59)
+            float t0, t1;
+            box_roots(pos, mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z), mk(op.v[0], op.v[1], op.v[2]), mk(op.v[3], op.v[4], op.v[5]), t0, t1);
+            if (!(t0 < t1 && t0 <= t_max && t1 >= 0.0f)) return false;
         }
     }
+    return true;
 }
 // Hit distance coming back out: Scale multiplies t (transform.rs:107).
 template <class Tab>
@@ -361,7 +367,7 @@ __device__ __forceinline__ void ops_hit_out(const Tab& tab, uint32_t first, uint
             pos = pos + mk(op.v[0], op.v[1], op.v[2]);
         } else if (op.kind == OP_SCALE) {
             pos = pos * op.v[0];
-        } else {
+        } else if (op.kind == OP_ROTATE) {
             pos = mat_apply(op.v, pos);
             nrm = mat_apply(op.v, nrm);
         }
@@ -445,7 +451,7 @@ __device__ __forceinline__ bool object_closest(const DevScene& S, const Mem* lds
     const GlobalTab tab{&S};
     const ObjHead ob = tab.object(oi);
     float tl_max = t_max;
-    ops_in(tab, ob.op_first, ob.op_count, pos, dir, tl_max);
+    if (!ops_in(tab, ob.op_first, ob.op_count, pos, dir, tl_max)) return false;
     float t = 0.0f, u = 0.0f, v = 0.0f;
     uint32_t prim = 0;
     bool hit = false;
@@ -473,7 +479,7 @@ template <class Mem>
 __device__ __forceinline__ bool object_any(const DevScene& S, const Mem* lds_mem, uint32_t oi, f3 pos, f3 dir, float t_max) {
     const GlobalTab tab{&S};
     const ObjHead ob = tab.object(oi);
-    ops_in(tab, ob.op_first, ob.op_count, pos, dir, t_max);
+    if (!ops_in(tab, ob.op_first, ob.op_count, pos, dir, t_max)) return false;
     if (ob.geom_kind == GEOM_MESH) {
         const DevMesh m = S.meshes[ob.geom_index];
         uint32_t prim; float u, v;
@@ -560,8 +566,8 @@ __device__ __forceinline__ bool scene_any(const DevScene& S, const Mem* lds_mem,
 __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b, f3 pos, f3 dir, f3& hpos, f3& hnorm, float& hu, float& hv) {
     const GlobalTab tab{&S};
     const ObjHead ob = tab.object(b.obj);
-    float dummy = 0.0f;
-    ops_in(tab, ob.op_first, ob.op_count, pos, dir, dummy);
+    float unbounded = __builtin_huge_valf();   // the ray got through every BoundingBox wrapper when it was traced
+    (void)ops_in(tab, ob.op_first, ob.op_count, pos, dir, unbounded);
     f3 p, n;
     hu = b.u; hv = b.v;
     if (ob.geom_kind == GEOM_MESH) {

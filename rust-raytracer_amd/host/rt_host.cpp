@@ -3,6 +3,7 @@
 // like the reference's f32 arithmetic, because tree shape and instance matrices feed the GPU kernels.
 #include "rt_host.hpp"
 
+#include <map>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -326,6 +327,27 @@ std::shared_ptr<Mesh> Mesh::from_vertices(const std::vector<Vec3D>& vertices, co
         mesh->tri_indices.insert(mesh->tri_indices.end(), {faces[face][0], faces[face][1], faces[face][2]});
     return mesh;
 }
+std::shared_ptr<Mesh> Mesh::from_triangles(const std::vector<std::array<Vec3D, 3>>& tris) {  // mesh.rs:83-116
+    std::vector<Vec3D> vertices;
+    std::vector<std::array<uint32_t, 3>> faces;
+    std::map<std::array<uint32_t, 3>, uint32_t> mapping;   // keyed by the bit pattern, as the reference's transmute to [u8; 12]
+    for (const auto& tri : tris) {
+        std::array<uint32_t, 3> face{};
+        for (int i = 0; i < 3; i++) {
+            std::array<uint32_t, 3> key;
+            const float v[3] = {tri[i].x, tri[i].y, tri[i].z};
+            std::memcpy(key.data(), v, 12);
+            auto it = mapping.find(key);
+            if (it == mapping.end()) {
+                it = mapping.emplace(key, (uint32_t)vertices.size()).first;
+                vertices.push_back(tri[i]);
+            }
+            face[i] = it->second;
+        }
+        faces.push_back(face);
+    }
+    return from_vertices(vertices, faces);
+}
 AABB Mesh::bounding_box() const {
     const rtamd_bvh_node& r = tree.nodes[0];
     return AABB(Vec3D(r.min[0], r.min[1], r.min[2]), Vec3D(r.max[0], r.max[1], r.max[2]));
@@ -397,6 +419,21 @@ void Rotate::flatten(FlatScene& fs, std::vector<rtamd_xform_op>& ops, uint32_t m
     rtamd_xform_op op{};
     op.kind = RTAMD_OP_ROTATE;
     std::memcpy(op.v, mat.m, sizeof(mat.m));
+    ops.push_back(op);
+    obj->flatten(fs, ops, material);
+    ops.pop_back();
+}
+BoundingBox::BoundingBox(GeomPtr o) : obj(o) {  // aggregate.rs:62-69
+    AABB bbox = o->bounding_box();
+    Vec3D delta = bbox.max - bbox.min;
+    Vec3D pad = Vec3D::fill(delta.x + delta.y * delta.z) * 0.001f;
+    box = AABB::from_points(bbox.min - pad, bbox.max + pad);
+}
+void BoundingBox::flatten(FlatScene& fs, std::vector<rtamd_xform_op>& ops, uint32_t material) const {
+    rtamd_xform_op op{};
+    op.kind = RTAMD_OP_BOUNDS;
+    op.v[0] = box.min.x; op.v[1] = box.min.y; op.v[2] = box.min.z;
+    op.v[3] = box.max.x; op.v[4] = box.max.y; op.v[5] = box.max.z;
     ops.push_back(op);
     obj->flatten(fs, ops, material);
     ops.pop_back();

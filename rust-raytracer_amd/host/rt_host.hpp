@@ -151,6 +151,8 @@ struct Mesh : Geometry, std::enable_shared_from_this<Mesh> {  // mesh.rs:16-81
     std::vector<uint32_t> face_of_prim;    // original face index of each tree-order triangle
     BvhTree tree;
     static std::shared_ptr<Mesh> from_vertices(const std::vector<Vec3D>& vertices, const std::vector<std::array<uint32_t, 3>>& faces);
+    // mesh.rs:83-116: vertices shared by bit pattern, numbered in order of first appearance
+    static std::shared_ptr<Mesh> from_triangles(const std::vector<std::array<Vec3D, 3>>& tris);
     AABB bounding_box() const override;
     void flatten(FlatScene& fs, std::vector<rtamd_xform_op>& ops, uint32_t material) const override;
 };
@@ -197,6 +199,13 @@ struct Rotate : Geometry {  // transform.rs:130-221
     GeomPtr obj; Mat3D mat;
     Rotate(GeomPtr o, Mat3D m) : obj(o), mat(m) {}
     AABB bounding_box() const override;
+    void flatten(FlatScene& fs, std::vector<rtamd_xform_op>& ops, uint32_t material) const override;
+};
+struct BoundingBox : Geometry {  // aggregate.rs:58-96: slab prefilter around an object, box padded by 0.001 * (dx + dy * dz)
+    GeomPtr obj; AABB box;
+    explicit BoundingBox(GeomPtr o);
+    static std::shared_ptr<BoundingBox> make(GeomPtr o) { return std::make_shared<BoundingBox>(o); }
+    AABB bounding_box() const override { return box; }
     void flatten(FlatScene& fs, std::vector<rtamd_xform_op>& ops, uint32_t material) const override;
 };
 struct Transform : Geometry {  // Translate<Scale<Rotate<T>>>, transform.rs:223-309

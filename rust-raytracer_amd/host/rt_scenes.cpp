@@ -167,6 +167,17 @@ Scene scene_textured(const std::string& ply_path, std::shared_ptr<const Image> s
                                                                     Vec3D(c.x + 1.5f, c.y, bb.min.z + 3.0f)),
                                          Lambartian(Checkerboard(4))));
     list.push_back(Object::with_material(Cuboid::make(vec3d(-5.0f, -5.0f, bb.min.z), vec3d(5.0f, 5.0f, bb.min.z - 1.0f)), Glossy(1e3f, 0.3f, Checkerboard(10))));
+    // BoundingBox prefilters (around a sphere, and inside a Translate around a flat triangle) and Mesh::from_triangles
+    list.push_back(Object::with_material(BoundingBox::make(Sphere(Vec3D(c.x - 1.0f, c.y + 3.6f, bb.min.z + 0.5f), 0.5f)), Metal()));
+    list.push_back(Object::with_material(
+        std::make_shared<Translate>(BoundingBox::make(std::make_shared<Triangle>(Vec3D(0.f, 0.f, 0.f), Vec3D(1.2f, 0.f, 0.f), Vec3D(0.f, 1.2f, 0.f))),
+                                    Vec3D(c.x - 3.0f, c.y - 3.0f, bb.min.z + 0.02f)),
+        Lambartian(UVTexture())));
+    {
+        Vec3D p0(0.f, 0.f, 0.f), p1(1.f, 0.f, 0.f), p2(0.f, 1.f, 0.f), p3(0.3f, 0.3f, 1.1f);
+        auto tetra = Mesh::from_triangles({{p0, p2, p1}, {p0, p1, p3}, {p1, p2, p3}, {p2, p0, p3}});
+        list.push_back(Object::with_material(std::make_shared<Translate>(tetra, Vec3D(c.x - 2.8f, c.y + 1.6f, bb.min.z)), Lambartian(Checkerboard(3))));
+    }
     Scene scene;
     for (auto& o : list) scene.root.push(o);
     Camera cam(cam_w, cam_h);

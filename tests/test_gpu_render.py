@@ -131,7 +131,8 @@ def test_terrain_scene_with_point_lights_renders(rt, ol, sky):
 
 
 def test_textured_scene_renders(rt, ol, sky):
-    """UVTexture, Checkerboard and Image textures on Lambartian / Glossy, Glass and a standalone Triangle; both integrator forms."""
+    """UVTexture, Checkerboard and Image textures on Lambartian / Glossy, Glass, a standalone Triangle, BoundingBox prefilters
+    and a Mesh::from_triangles mesh; both integrator forms."""
     cam = (200, 160)
     tex = (np.arange(37 * 53 * 3) * 7 % 256).astype(np.uint8).reshape(37, 53, 3)
     for t in (tex, None):
@@ -139,7 +140,8 @@ def test_textured_scene_renders(rt, ol, sky):
         rays = cpu.primary_rays(0, 0, cam[0], cam[1])
         c = cpu.trace_closest(rays)
         check_closest(rt, gpu.trace_closest(rays), c, exact_uv=False)   # spheres: u, v through atan2 / acos
-        assert set(np.unique(c["obj"])) >= {0, 1, 2, 3, 4, 5}   # every object is in view
+        assert set(np.unique(c["obj"])) >= set(range(9))   # every object is in view, the BoundingBox-wrapped ones included
+        assert np.array_equal(gpu.trace_any(rays), cpu.trace_any(rays)[0])
         for params in (dict(max_depth=4, shadow_rays=1, antialiasing=2), dict(max_depth=3, shadow_rays=1, scatter_rays=2, antialiasing=1)):
             img, _ = gpu.render(**params)
             ref, _, _ = cpu.render(**params)
