@@ -406,15 +406,15 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 // (3) enter the next object
                 if (st == ST_OBJ && o_cur < o_end) {
                     oi = o_cur++;
-                    const ObjHead ob = tab.object(oi);
+                    ObjHead ob = tab.object(oi);
                     const ObjXf xf = tab.object_xf(oi);   // read with the head: one LDS round trip instead of two
                     opos = wpos; otmax = wtmax;
                     odir = wdir;
                     oscale = ob.scale;
-                    bool enter = true;   // false: a BoundingBox wrapper turns the ray away
                     if (ob.xf_kind & XF_GENERIC) {
                         fl |= F_GENXF;
-                        enter = ops_in(tab, ob.op_first, ob.op_count, opos, odir, otmax);
+                        // a BoundingBox wrapper that turns the ray away: go on as for a mesh without nodes
+                        if (!ops_in(tab, ob.op_first, ob.op_count, opos, odir, otmax)) { ob.geom_kind = GEOM_MESH; ob.n_nodes = 0u; }
                     } else {
                         fl &= ~F_GENXF;
                         xf_in_pos(ob.xf_kind, xf, ob.inv_scale, opos, otmax);
@@ -426,17 +426,17 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
                         if (MESHLOC == MESH_MIXED) fl = (ob.geom_index == S.lds_mesh) ? (fl | F_MLDS) : (fl & ~F_MLDS);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
-                        if (n_n > 0 && enter) node_step();
+                        if (n_n > 0) node_step();
                         DIAG_SUB_END(5)
                     } else {
                         float t = 0.0f;
                         bool hit;
                         if (fl & F_ANY) {
-                            hit = enter && primitive_any(S, tab, ob, opos, odir, otmax);
+                            hit = primitive_any(S, tab, ob, opos, odir, otmax);
                             if (hit) { fl |= F_OCC | F_HAVE; st = ST_FETCH; }
                         } else {
                             float u = 0.f, v = 0.f;
-                            hit = enter && primitive_closest(S, tab, ob, opos, odir, otmax, t, u, v);
+                            hit = primitive_closest(S, tab, ob, opos, odir, otmax, t, u, v);
                             if (hit) {
                                 best.obj = oi; best.prim = 0; best.t_local = t; best.u = u; best.v = v;
                                 wtmax = (fl & F_GENXF) ? ops_t_out(tab, ob.op_first, ob.op_count, t) : t * ob.scale;
