@@ -404,6 +404,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         d.op_first = ob.op_first; d.op_count = ob.op_count;
         if (ob.geom_kind == RTAMD_GEOM_MESH) {
             d.node_base = meshes[ob.geom_index].node_base; d.n_nodes = meshes[ob.geom_index].n_nodes; d.tri_base = meshes[ob.geom_index].tri_base;
+            d.normal_base = meshes[ob.geom_index].normal_base;
         }
         // inline wrapper parameters when the chain is a subsequence of Translate, Scale, Rotate
         d.scale = 1.0f; d.inv_scale = 1.0f;
@@ -876,6 +877,15 @@ int rtamd_diag_read(rtamd_context* ctx, unsigned long long out[32], int reset) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, rtamd::diag_read(out, reset));
+    return RTAMD_OK;
+}
+// Ticks (10 ns) along the shade kernel's dependency chain as seen by its first thread: out[k] summed over launches,
+// out[16 + k] the launch count; k = 0 loads + classification, 2 lit-queue append, 3 light samples, 5 scatter, 7 path-queue append.
+int rtamd_diag_read_shade(rtamd_context* ctx, unsigned long long out[32], int reset) {
+    if (!ctx) return RTAMD_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, rtamd::diag_read_shade(out, reset));
     return RTAMD_OK;
 }
 #endif

@@ -40,7 +40,7 @@ struct DevOp { uint32_t kind; float v[9]; uint32_t pad[2]; };
 struct DevObject {
     uint32_t geom_kind, geom_index, material, xf_kind;
     uint32_t op_first, op_count, node_base, n_nodes;
-    uint32_t tri_base; float scale, inv_scale; uint32_t pad;
+    uint32_t tri_base; float scale, inv_scale; uint32_t normal_base;
     float off[3]; float rot[9];
 };
 enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8 };
@@ -275,7 +275,7 @@ struct CuboidRec { f3 center, extent, inv_extent; };
 
 // Head of an object record (the first three float4) and its inline wrapper parameters (the last three).
 struct ObjHead {
-    uint32_t geom_kind, geom_index, material, xf_kind, op_first, op_count, node_base, n_nodes, tri_base;
+    uint32_t geom_kind, geom_index, material, xf_kind, op_first, op_count, node_base, n_nodes, tri_base, normal_base;
     float scale, inv_scale;
 };
 struct ObjXf { f3 off; float rot[9]; };
@@ -283,7 +283,7 @@ __device__ __forceinline__ ObjHead unpack_object(float4 a, float4 b, float4 c) {
     ObjHead o;
     o.geom_kind = __float_as_uint(a.x); o.geom_index = __float_as_uint(a.y); o.material = __float_as_uint(a.z); o.xf_kind = __float_as_uint(a.w);
     o.op_first = __float_as_uint(b.x); o.op_count = __float_as_uint(b.y); o.node_base = __float_as_uint(b.z); o.n_nodes = __float_as_uint(b.w);
-    o.tri_base = __float_as_uint(c.x); o.scale = c.y; o.inv_scale = c.z;
+    o.tri_base = __float_as_uint(c.x); o.scale = c.y; o.inv_scale = c.z; o.normal_base = __float_as_uint(c.w);
     return o;
 }
 __device__ __forceinline__ ObjXf unpack_xf(float4 d, float4 e, float4 f) {
@@ -571,9 +571,8 @@ __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b
     f3 p, n;
     hu = b.u; hv = b.v;
     if (ob.geom_kind == GEOM_MESH) {
-        const DevMesh m = S.meshes[ob.geom_index];
-        float4 q2 = S.tris[3 * ((size_t)m.tri_base + b.prim) + 2];
-        const float4* nr = S.normals + m.normal_base;
+        float4 q2 = S.tris[3 * ((size_t)ob.tri_base + b.prim) + 2];
+        const float4* nr = S.normals + ob.normal_base;
         float4 na = nr[__float_as_uint(q2.y)], nb = nr[__float_as_uint(q2.z)], nc = nr[__float_as_uint(q2.w)];
         float w = 1.0f - b.u - b.v;
         n = (w * mk(na.x, na.y, na.z) + b.u * mk(nb.x, nb.y, nb.z)) + b.v * mk(nc.x, nc.y, nc.z);

@@ -120,6 +120,7 @@ hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, con
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 #ifdef RTAMD_DIAG
 hipError_t diag_read(unsigned long long* out, int reset);
+hipError_t diag_read_shade(unsigned long long* out, int reset);
 #endif
 
 }  // namespace rtamd

@@ -385,6 +385,17 @@ __device__ __forceinline__ void light_sample(const DevLight& l, f3 pos, f3 norma
     }
 }
 
+// Diagnostic build only: time stamps (s_memtime, 100 MHz) along the shade kernel's dependency chain, taken by the
+// first thread of the first block; slot k accumulates the ticks between probe k-1 and probe k, slot 16 + k counts.
+#ifdef RTAMD_DIAG
+__device__ unsigned long long g_shade_diag[32];
+#define SHADE_PROBE_DECL unsigned long long sp_t = __builtin_amdgcn_s_memtime(); const bool sp_on = blockIdx.x == 0 && threadIdx.x == 0;
+#define SHADE_PROBE(k) { unsigned long long sp_n = __builtin_amdgcn_s_memtime(); if (sp_on) { g_shade_diag[k] += sp_n - sp_t; g_shade_diag[16 + k] += 1; } sp_t = sp_n; }
+#else
+#define SHADE_PROBE_DECL
+#define SHADE_PROBE(k)
+#endif
+
 // Block-wide compaction: threads with `take` get consecutive slots of a global queue.  The waves
 // of a block pool their counts in LDS and the block issues ONE atomic.  A single queue counter sustains only ~90 atomics/us, so stages that
 // append from every wave are bound by it unless they aggregate.  Every thread of the block must
@@ -608,6 +619,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
 __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
                                                     uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot) {
     __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
+    SHADE_PROBE_DECL
     const uint32_t n = W.counts[q_in_idx];
     const bool odd = (depth & 1) != 0;
     const float* r = fold ? W.p_ray : (odd ? W.q_ray[1] : W.q_ray[0]);
@@ -667,8 +679,10 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
         // Every lit hit emits the same number of shadow rays (`n_shoot`, the samples of the lights that can need one), so
         // the shadow-ray queue needs no compaction of its own: the block's rays go to [lbase * n_shoot, (lbase + lcnt) *
         // n_shoot), grouped by sample.
+        SHADE_PROBE(0 + (__float_as_uint(diffuse.x) == 0x7fc12345u))   // the classification is done: waits for phase A's loads
         uint32_t lbase, lcnt;
         uint32_t lq = block_append_range<STAGE_BLOCK / 64>(lit, &W.counts[lit_idx], &W.counts[any_idx], n_shoot, sh_app, lbase, lcnt);
+        SHADE_PROBE(2)
         // ---- phase B: draw light samples, then the scatter direction (same stream order) ----
         f3 next_pos = mk(0, 0, 0), next_dir = mk(0, 0, 0);
         Rng rng; rng.lo = 0; rng.hi = 0;
@@ -707,6 +721,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
                 }
             }
         }
+        SHADE_PROBE(3 + (rng.lo == 0x123456789abcull && lit))   // light samples drawn
         if (hit) {
             const DevMaterial m = S.materials[mat];
             f3 out, w;
@@ -724,8 +739,10 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
             }
             W.rng_lo[slot] = rng.lo; W.rng_hi[slot] = rng.hi;
         }
+        SHADE_PROBE(5 + (cont && rng.lo == 0x123456789abcull))      // scatter direction drawn
         // ---- compaction of the continuing paths into the next ray queue ----
         uint32_t nq = block_append<STAGE_BLOCK / 64>(cont, &W.counts[q_out_idx], sh_app);
+        SHADE_PROBE(7)
         if (cont) {
             q_slot_out[nq] = slot;
             float* o = q_ray_out;
@@ -1104,6 +1121,15 @@ hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t
 }
 
 #ifdef RTAMD_DIAG
+hipError_t diag_read_shade(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shade_diag), 256);
+    if (e != hipSuccess) return e;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_shade_diag), z, 256);
+    }
+    return e;
+}
 hipError_t diag_read(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), 256);
     if (e != hipSuccess) return e;

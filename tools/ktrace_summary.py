@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Per-kernel duration statistics from a rocprofv3 --kernel-trace --output-format csv directory:
+count, total, min / p10 / median / p90 / max per launch, the idle gaps between kernels, and the durations of a few
+consecutive trace and shade launches in launch order (one sample pass is four trace and five shade launches).
+Usage: python tools/ktrace_summary.py <output dir of rocprofv3>"""
 import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -19,3 +24,9 @@ for r in rows:
         if 0 < g < 1e6: gap += g
     prev = max(prev or 0, int(r['End_Timestamp']))
 print("idle gaps between kernels (<1ms each): %.2f ms over %d kernels" % (gap / 1e6, len(rows)))
+tr = [r for r in rows if 'k_wave_trace' in r['Kernel_Name']]
+tr.sort(key=lambda r: int(r['Start_Timestamp']))
+print("trace launches 200..216 (us):", [round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3) for r in tr[200:216]])
+sh = [r for r in rows if 'k_wave_shade' in r['Kernel_Name']]
+sh.sort(key=lambda r: int(r['Start_Timestamp']))
+print("shade launches 200..215 (us):", [round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3) for r in sh[200:215]])

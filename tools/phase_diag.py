@@ -38,11 +38,15 @@ def main():
     lib = rt.rtamd_lib()
     lib.rtamd_diag_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
     buf = (C.c_uint64 * 32)()
+    lib.rtamd_diag_read_shade.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    sbuf = (C.c_uint64 * 32)()
     for depth in sorted({1, args.depth}):
         scene.render(max_depth=depth, antialiasing=1)  # warm up
         lib.rtamd_diag_read(scene.ctx, buf, 1)
+        lib.rtamd_diag_read_shade(scene.ctx, sbuf, 1)
         _, st = scene.render(max_depth=depth, shadow_rays=1, antialiasing=args.aa)
         lib.rtamd_diag_read(scene.ctx, buf, 1)
+        lib.rtamd_diag_read_shade(scene.ctx, sbuf, 1)
         d = np.array(list(buf), dtype=np.float64)[:15].reshape(5, 3)
         rays = st["closest_rays"] + st["any_rays"]
         total = d[:, 0].sum()
@@ -55,6 +59,13 @@ def main():
         for name, (cyc, cnt) in zip(("fetch: wait for staged batch", "fetch: queue-head atomic", "fetch: result stores", "obj: fold + next object", "obj: record + wrappers", "obj: mesh entry + root box", "-", "-"), sub):
             if cnt:
                 print(f"  {name:30s} {100 * cyc / total:5.1f}% of cycles  n {int(cnt):>10d}  cycles each {cyc / cnt:8.1f}")
+        sh = np.array(list(sbuf), dtype=np.float64)
+        names = {0: "loads + hit reconstruction", 2: "lit-queue append", 3: "light samples", 5: "scatter", 7: "path-queue append"}
+        if sh[16:].sum():
+            print("  shade kernel, first thread of the first block, microseconds per launch:")
+            for k, name in names.items():
+                if sh[16 + k]:
+                    print(f"    {name:28s} {sh[k] / sh[16 + k] / 100.0:7.2f} us  (launches {int(sh[16 + k])})")
 
 
 if __name__ == "__main__":
