@@ -40,6 +40,17 @@ enum : int { MESH_GLOBAL = 0, MESH_LDS = 1, MESH_MIXED = 2 };
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
+#ifndef RTAMD_NODE_STAY_NUM
+#define RTAMD_NODE_STAY_NUM 1
+#endif
+#ifndef RTAMD_NODE_STAY_DEN
+#define RTAMD_NODE_STAY_DEN 4
+#endif
+#ifndef RTAMD_OBJ_STAY_NUM
+#define RTAMD_OBJ_STAY_NUM 3
+#endif
+static constexpr uint32_t OBJ_STAY_NUM = RTAMD_OBJ_STAY_NUM;
+static constexpr uint32_t NODE_STAY_NUM = RTAMD_NODE_STAY_NUM, NODE_STAY_DEN = RTAMD_NODE_STAY_DEN;
 // Vote weights (TRI, NODE, OBJ, FETCH, TNODE): a phase's lane count is multiplied by its weight before the
 // comparison, so a phase with a low weight waits until it has gathered proportionally more lanes.  The OBJ and
 // FETCH steps are several times longer than a NODE step; with these weights they run once the tree walks of
@@ -344,7 +355,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             }
           }
         } else if (phase == ST_NODE) {
-          for (uint32_t c = c_node; c * STAY_DEN >= c_node * STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
+          for (uint32_t c = c_node; c * NODE_STAY_DEN >= c_node * NODE_STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
             if (st == ST_NODE) node_step();
           }
@@ -369,7 +380,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         } else if (phase == ST_OBJ) {
           // A lane stays in this phase across objects that end at once: a primitive that is not a mesh, or a mesh
           // whose root box the ray misses (most instances, for most rays): its root is tested right here.
-          for (uint32_t c = c_obj; c * STAY_DEN >= c_obj * STAY_NUM && c > 0; c = wave_count(st == ST_OBJ)) {
+          for (uint32_t c = c_obj; c * STAY_DEN >= c_obj * OBJ_STAY_NUM && c > 0; c = wave_count(st == ST_OBJ)) {
             DIAG_STEP(ST_OBJ, c)
             DIAG_SUB_BEGIN
             if (st == ST_OBJ) {
