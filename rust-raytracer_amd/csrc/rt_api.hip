@@ -163,6 +163,7 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
     if ((rc = wave_alloc(ctx, ws, &W.p_slot, cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.p_ray, 6 * cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.p_rec, 2 * cap))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.p_pix, cap))) return rc;
     for (int k = 0; k < 2; k++) {
         ShadeSet& T = W.set[k];
         if ((rc = wave_alloc(ctx, ws, &T.lit_slot, cap))) return rc;
@@ -172,7 +173,7 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
         if ((rc = wave_alloc(ctx, ws, &T.a_vidx, S * cap))) return rc;
         if ((rc = wave_alloc(ctx, ws, &T.vis, S * cap))) return rc;
     }
-    if ((rc = wave_alloc(ctx, ws, &W.counts, (size_t)3 * CounterSlots::TOTAL))) return rc;
+    if ((rc = wave_alloc(ctx, ws, &W.counts, (size_t)CounterSlots::WORDS))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.stats, (size_t)16))) return rc;
     ws.cap = cap; ws.samples = samples;
     return RTAMD_OK;
@@ -763,20 +764,33 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     continue;
                 }
                 const uint32_t fold = pass >= 2 ? 2u : 1u;
+                // max_depth >= 2: the primary queue is built once (pass 0) and kept; the shade launch of bounce 0 rewrites its
+                // ray directions for the next pass and zeroes the next pass's counter set, so a pass launches neither a
+                // ray-generation kernel nor a memset
+                const bool kept = D >= 2;
+                const uint32_t pq = kept ? CS::PQ_KEPT : cb + CS::PQ;
+                NextPass next{};
+                next.zero_base = MISS;
+                if (kept && pass + 1 < n_pass) {
+                    next.enabled = 1u; next.si = (pass + 1) / aa; next.sj = (pass + 1) % aa; next.aa = aa;
+                    next.zero_base = nb;
+                    next.cam = C;
+                }
+                const NextPass none{0u, 0u, 0u, 0u, MISS, C};
                 if (pass == 0 || D < 2) {  // otherwise the pass before has generated and traced this pass's primary rays
-                    HIP_TRY(ctx, hipMemsetAsync(W.counts + cb, 0, CS::TOTAL * 4, st));
-                    HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, pass / aa, pass % aa, aa, pass == 0, cb + CS::PQ, st));
+                    HIP_TRY(ctx, hipMemsetAsync(W.counts + (kept ? 0u : cb), 0, (kept ? CS::WORDS : CS::TOTAL) * 4, st));
+                    HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, pass / aa, pass % aa, aa, pass == 0, pq, st));
                     launches++;
                     if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
                         HIP_TRY(ctx, launch_mark_miss(W, cb + CS::PQ, chunk_n, st));
-                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, 1, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, 1, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, none, chunk_n, st));
                         launches += 2;
                         continue;
                     }
                     // primary rays; with max_depth = 1 also the shadow rays of the previous pass (its only bounce: set 1)
                     const bool carry = D == 1 && pass > 0;
                     timed_begin(ctx, 0, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, 0, MISS, cb + CS::PQ, MISS, carry ? pb + CS::ANY + 0 : MISS, cb + CS::HEAD + 0,
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, 0, MISS, pq, MISS, carry ? pb + CS::ANY + 0 : MISS, cb + CS::HEAD + 0,
                                                    chunk_n + (carry ? any_upper : 0), st));
                     timed_end(ctx, st);
                     launches++;
@@ -786,23 +800,18 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     }
                 }
                 timed_begin(ctx, 2, st);
-                HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, D, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, chunk_n, st));
+                HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, D, sr, fold, pq, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, next, chunk_n, st));
                 timed_end(ctx, st);
                 launches++;
                 for (int d = 1; d < D; d++) {
                     const bool ahead = d == D - 1 && pass + 1 < n_pass;   // the next pass's primary rays ride with this launch
-                    if (ahead) {
-                        HIP_TRY(ctx, hipMemsetAsync(W.counts + nb, 0, CS::TOTAL * 4, st));
-                        HIP_TRY(ctx, launch_raygen(W, R, C, (uint32_t)begin, chunk_n, (pass + 1) / aa, (pass + 1) % aa, aa, false, nb + CS::PQ, st));
-                        launches++;
-                    }
                     // closest-hit rays of bounce d with the shadow rays of the bounce before; bounce 1 also takes the shadow
                     // rays that the previous pass's last bounce left in set 0
                     const bool carry = d == 1 && pass > 0;
                     const uint32_t a0 = d == 1 ? (carry ? pb + CS::ANY + (D - 1) : MISS) : cb + CS::ANY + (d - 1);
                     const uint32_t a1 = d == 1 ? cb + CS::ANY + 0 : MISS;
                     timed_begin(ctx, 0, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, (uint32_t)(d & 1), cb + CS::Q + d, ahead ? nb + CS::PQ : MISS, a0, a1, cb + CS::HEAD + d,
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, (uint32_t)(d & 1), cb + CS::Q + d, ahead ? pq : MISS, a0, a1, cb + CS::HEAD + d,
                                                    chunk_n + (ahead ? chunk_n : 0) + (a0 != MISS ? any_upper : 0) + (a1 != MISS ? any_upper : 0), st));
                     timed_end(ctx, st);
                     launches++;
@@ -813,7 +822,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     }
                     HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, sr, cb + CS::LIT + (d - 1), d == 1 ? 1u : 0u, chunk_n, st));
                     launches++;
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, S_shoot, chunk_n, st));
+                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, S_shoot, none, chunk_n, st));
                     timed_end(ctx, st);
                     launches++;
                 }

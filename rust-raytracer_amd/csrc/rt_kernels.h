@@ -56,6 +56,8 @@ struct WaveBufs {
     uint32_t* p_slot;     // cap
     float* p_ray;         // 6*cap
     uint4* p_rec;         // 2*cap
+    uint2* p_pix;         // cap: pixel (cx, cy) of the queue entry; every valid pixel has one primary ray per pass, so the
+                          // queue keeps its entries over the passes and only the ray directions are rewritten
     // One 32-byte record per path: {object index or MISS, primitive, t in the object's space, u} {v, -, -, -}.
     // Rays of a wave finish in no particular order, so their results are scattered writes; as one
     // record they touch one cache line per ray instead of five.
@@ -79,6 +81,15 @@ struct CounterSlots {
     static constexpr uint32_t HEAD = ANY + MAX_DEPTH;   // HEAD + d: work-queue head of trace launch d
     static constexpr uint32_t PQ = HEAD + MAX_DEPTH + 1;  // primary rays of the pass
     static constexpr uint32_t TOTAL = PQ + 1;
+    static constexpr uint32_t PQ_KEPT = 3 * TOTAL;        // behind the three sets: length of a primary queue that is kept over the passes
+    static constexpr uint32_t WORDS = 3 * TOTAL + 1;
+};
+// What the shade launch of bounce 0 does for the pass after it (max_depth >= 2): rewrite the primary ray directions for
+// that pass's sample and zero that pass's counter set.
+struct NextPass {
+    uint32_t enabled, si, sj, aa;
+    uint32_t zero_base;   // first counter of the set to zero, or MISS
+    CameraDev cam;
 };
 
 struct LaunchCfg {
@@ -106,7 +117,8 @@ hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const Wave
 // two passes back) to the pixel sum first, then W.L and the throughput are reset; other depths use set 0.
 // n_shoot: shadow rays per lit hit = light samples of the lights that can need one (not ambient, not reach 0).
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
-                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, size_t upper, hipStream_t st);
+                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, const NextPass& next, size_t upper,
+                             hipStream_t st);
 hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set,
                                size_t upper, hipStream_t st);
 // pixel = (sum + L_first + L_second) / n_samples; L_first may be null (a single sample pass)

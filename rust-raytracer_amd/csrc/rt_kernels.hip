@@ -483,6 +483,17 @@ __device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, ui
     return px < R.w && py < R.h && tile < R.n_tiles;
 }
 
+// Direction of the camera ray through sample (si, sj) of pixel (cx, cy): integrator.rs:41-42, scene.rs:84-90.
+__device__ __forceinline__ f3 primary_dir(const CameraDev& cam, uint32_t cx, uint32_t cy, uint32_t si, uint32_t sj, uint32_t aa) {
+    float n = (float)aa;
+    float x = (float)cx + ((float)si + 0.5f) / n - 0.5f;
+    float y = (float)cy + ((float)sj + 0.5f) / n - 0.5f;
+    float u = 2.0f * (x / (float)cam.width) - 1.0f;
+    float v = 2.0f * (y / (float)cam.height) - 1.0f;
+    f3 d = (cam.dir + u * cam.horizontal) + v * cam.vertical;
+    return normalize(d);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stage 1: ray generation.  One lane per pixel slot of the chunk; sample (si, sj) of the regular
 // antialiasing grid (src/integrator.rs:33-48).  Primary rays depend on nothing but the pixel and the
@@ -505,18 +516,13 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R,
             W.rng_lo[i] = r.lo; W.rng_hi[i] = r.hi;
             W.sum[i] = 0.0f; W.sum[i + W.cap] = 0.0f; W.sum[i + 2 * W.cap] = 0.0f;
         }
-        float n = (float)aa;
-        float x = (float)cx + ((float)si + 0.5f) / n - 0.5f;  // integrator.rs:41-42
-        float y = (float)cy + ((float)sj + 0.5f) / n - 0.5f;
-        float u = 2.0f * (x / (float)cam.width) - 1.0f;       // scene.rs:84-90
-        float v = 2.0f * (y / (float)cam.height) - 1.0f;
-        f3 d = (cam.dir + u * cam.horizontal) + v * cam.vertical;
-        dir = normalize(d);
+        dir = primary_dir(cam, cx, cy, si, sj, aa);
         pos = cam.pos;
     }
     uint32_t q = block_append<STAGE_BLOCK / 64>(valid, &W.counts[p_idx], sh_app);
     if (valid) {
         W.p_slot[q] = i;
+        W.p_pix[q] = make_uint2(cx, cy);
         float* r = W.p_ray;
         r[q] = pos.x; r[q + W.cap] = pos.y; r[q + 2 * W.cap] = pos.z;
         r[q + 3 * W.cap] = dir.x; r[q + 4 * W.cap] = dir.y; r[q + 5 * W.cap] = dir.z;
@@ -617,10 +623,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
 // sample: fold 2 adds the radiance buffer's old content (the sample two passes back, complete by now) to the
 // pixel sum in generation order (integrator.rs:50-53), fold 1 and 2 zero the buffer; the throughput starts at 1.
 __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
-                                                    uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot) {
+                                                    uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot,
+                                                    NextPass next) {
     __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
     SHADE_PROBE_DECL
     const uint32_t n = W.counts[q_in_idx];
+    if (next.zero_base != MISS && blockIdx.x == 0)   // nothing reads or appends to that set before this launch is over
+        for (uint32_t k = threadIdx.x; k < CounterSlots::TOTAL; k += blockDim.x) W.counts[next.zero_base + k] = 0u;
     const bool odd = (depth & 1) != 0;
     const float* r = fold ? W.p_ray : (odd ? W.q_ray[1] : W.q_ray[0]);
     const uint32_t* q_slot_in = fold ? W.p_slot : (odd ? W.q_slot[1] : W.q_slot[0]);
@@ -643,6 +652,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
             slot = q_slot_in[i];
             f3 pos = mk(r[i], r[i + cap], r[i + 2 * cap]);
             dir = mk(r[i + 3 * cap], r[i + 4 * cap], r[i + 5 * cap]);
+            if (next.enabled) {   // this entry's primary ray of the next pass (same origin: only the direction changes)
+                const uint2 px = W.p_pix[i];
+                const f3 nd = primary_dir(next.cam, px.x, px.y, next.si, next.sj, next.aa);
+                W.p_ray[i + 3 * cap] = nd.x; W.p_ray[i + 4 * cap] = nd.y; W.p_ray[i + 5 * cap] = nd.z;
+            }
             if (fold) {
                 if (fold == 2u) {
                     W.sum[slot] = W.sum[slot] + W.L[slot];
@@ -1076,14 +1090,15 @@ hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const Wave
     return hipGetLastError();
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
-                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, size_t upper, hipStream_t st) {
+                             uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, const NextPass& next, size_t upper,
+                             hipStream_t st) {
     size_t need = (upper + STAGE_BLOCK - 1) / STAGE_BLOCK;
     size_t capg = (size_t)cfg.num_cus * (2048 / STAGE_BLOCK);
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
     // bounce 0 fills shade set 1, the other bounces set 0
     hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, W.set[fold ? 1 : 0], depth, max_depth, shadow_rays, fold, q_in, q_out,
-                       lit_idx, any_idx, n_shoot);
+                       lit_idx, any_idx, n_shoot, next);
     return hipGetLastError();
 }
 hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set, size_t upper,
