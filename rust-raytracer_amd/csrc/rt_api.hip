@@ -2,10 +2,12 @@
 // Host side only: context, scene upload (reference layout -> device layout), launch sequencing.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -107,6 +109,67 @@ int convert_tree(rtamd_context* ctx, const rtamd_bvh_node* nodes, uint32_t n_nod
         out.push_back(make_float4(nd.max[1], nd.max[2], fa, fb));
     }
     return RTAMD_OK;
+}
+
+// The padded box of an object in the space of the scene's rays (see DevObject): the primitive's own bounds carried out
+// through the wrappers, innermost first, in double precision, then padded by 1e-4 of its size (the float rounding of
+// the reference's own transforms is orders of magnitude below that).  slack = 0.011 x the chain's scale: the visit test
+// of the trees lets t run 0.01 beyond the box in the object's t (bvh.rs:231), and t grows by `scale` on the way out
+// (transform.rs:104-107).
+void object_box(const rtamd_scene_desc* sc, const rtamd_object& ob, const std::vector<float4>& nodes, const std::vector<DevMesh>& meshes, DevObject& d) {
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int k = 0; k < 3; k++) { d.bmin[k] = -inf; d.bmax[k] = inf; }
+    d.slack = inf;
+    double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};   // unit sphere, unit cuboid
+    if (ob.geom_kind == RTAMD_GEOM_MESH) {
+        const float4 n0 = nodes[2 * (size_t)meshes[ob.geom_index].node_base], n1 = nodes[2 * (size_t)meshes[ob.geom_index].node_base + 1];
+        lo[0] = n0.x; lo[1] = n0.y; lo[2] = n0.z; hi[0] = n0.w; hi[1] = n1.x; hi[2] = n1.y;
+    } else if (ob.geom_kind == RTAMD_GEOM_CUBOID) {
+        const rtamd_cuboid& c = sc->cuboids[ob.geom_index];
+        for (int k = 0; k < 3; k++) { lo[k] = (double)c.center[k] - std::fabs((double)c.extent[k]); hi[k] = (double)c.center[k] + std::fabs((double)c.extent[k]); }
+    } else if (ob.geom_kind == RTAMD_GEOM_TRIANGLE) {
+        const rtamd_triangle& t = sc->triangles[ob.geom_index];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min({(double)t.a[k], (double)t.b[k], (double)t.c[k]});
+            hi[k] = std::max({(double)t.a[k], (double)t.b[k], (double)t.c[k]});
+        }
+    }
+    double scale = 1.0;
+    for (uint32_t q = ob.op_count; q-- > 0;) {
+        const rtamd_xform_op& op = sc->ops[ob.op_first + q];
+        if (op.kind == RTAMD_OP_TRANSLATE) {
+            for (int k = 0; k < 3; k++) { lo[k] += op.v[k]; hi[k] += op.v[k]; }
+        } else if (op.kind == RTAMD_OP_SCALE) {
+            if (!(op.v[0] > 0.0f)) return;   // mirrored or degenerate: no box
+            scale *= op.v[0];
+            for (int k = 0; k < 3; k++) { lo[k] *= op.v[0]; hi[k] *= op.v[0]; }
+        } else if (op.kind == RTAMD_OP_ROTATE) {
+            double nlo[3] = {1e300, 1e300, 1e300}, nhi[3] = {-1e300, -1e300, -1e300};
+            for (int c = 0; c < 8; c++) {
+                const double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+                for (int i = 0; i < 3; i++) {
+                    const double v = (double)op.v[3 * i] * p[0] + (double)op.v[3 * i + 1] * p[1] + (double)op.v[3 * i + 2] * p[2];
+                    nlo[i] = std::min(nlo[i], v); nhi[i] = std::max(nhi[i], v);
+                }
+            }
+            for (int k = 0; k < 3; k++) { lo[k] = nlo[k]; hi[k] = nhi[k]; }
+        }   // BOUNDS: the object's own bounds are what counts
+    }
+    double size = 0.0;
+    for (int k = 0; k < 3; k++) {
+        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) return;
+        size = std::max({size, hi[k] - lo[k], std::fabs(lo[k]), std::fabs(hi[k])});
+    }
+    const double pad = 1e-4 * size + 1e-6;
+    for (int k = 0; k < 3; k++) {
+        d.bmin[k] = std::nextafter((float)(lo[k] - pad), -inf);
+        d.bmax[k] = std::nextafter((float)(hi[k] + pad), inf);
+    }
+    d.slack = (float)(0.011 * scale + 1e-6);
+    // worth testing where entering is costly and missing is likely: a mesh under a rotation
+    bool rotated = false;
+    for (uint32_t q = 0; q < ob.op_count; q++) rotated = rotated || sc->ops[ob.op_first + q].kind == RTAMD_OP_ROTATE;
+    if (ob.geom_kind == RTAMD_GEOM_MESH && rotated) d.xf_kind |= XF_BOX;
 }
 
 int ensure_batch(rtamd_context* ctx, size_t bytes) {
@@ -421,6 +484,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
             else std::memcpy(d.rot, op.v, 36);
         }
         if (d.xf_kind == XF_GENERIC) { d.scale = 1.0f; d.inv_scale = 1.0f; }
+        object_box(sc, ob, nodes, meshes, d);
         objects.push_back(d);
     }
     std::vector<DevOp> ops;
@@ -523,6 +587,8 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     }
     // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
+    S.any_box = 0;
+    for (const DevObject& o : objects) S.any_box |= (o.xf_kind & XF_BOX) ? 1u : 0u;
     // a root list of plain objects with consecutive indices is walked as one range, without reading the list
     S.root_first = MISS;
     if (sc->n_root > 0 && sc->root[0].kind == RTAMD_ROOT_OBJECT) {

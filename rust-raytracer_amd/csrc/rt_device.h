@@ -42,8 +42,15 @@ struct DevObject {
     uint32_t op_first, op_count, node_base, n_nodes;
     uint32_t tri_base; float scale, inv_scale; uint32_t normal_base;
     float off[3]; float rot[9];
+    // A padded box around the object in the space of the scene's rays, and the reach of the tree's visit slack in
+    // that space's t (0.01 in the object's t, bvh.rs:231, times the chain's scale, plus a margin).  A ray whose slab
+    // interval of this box is empty or lies outside [-slack, t_max + slack] cannot pass the object's own first test
+    // after the wrappers, so the scheduler kernels skip the object without entering it.  Only objects that are costly
+    // to enter and easy to miss (meshes under a rotation) are flagged XF_BOX; the others are entered directly.
+    float bmin[3], bmax[3]; float slack; uint32_t pad1;
 };
-enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8 };
+static_assert(sizeof(DevObject) == 128, "object record = 8 float4");
+enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8, XF_BOX = 16 /* test the object's box (bmin, bmax) before entering */ };
 struct DevRootItem { uint32_t kind, index; };
 struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t tex_kind; int32_t tex_param; };
 struct DevImage { uint32_t first, w, h, pad; };   // texels at sky[first ...], row-major
@@ -77,6 +84,7 @@ struct DevScene {
     uint32_t lds_mesh;        // mesh index staged in LDS by the trace kernels, or MISS
     uint32_t lds_bytes;       // bytes of LDS needed for that mesh
     uint32_t n_ops, n_cuboids;
+    uint32_t any_box;         // some object carries XF_BOX: rays get their reciprocal direction when they are fetched
     uint32_t tab_bytes;       // bytes of LDS for the scene tables (objects, ops, cuboids, root), 0 = keep them in global memory
 };
 
@@ -279,6 +287,12 @@ struct ObjHead {
     float scale, inv_scale;
 };
 struct ObjXf { f3 off; float rot[9]; };
+struct ObjBox { f3 mn, mx; float slack; };
+__device__ __forceinline__ ObjBox unpack_box(float4 g, float4 h) {
+    ObjBox b;
+    b.mn = mk(g.x, g.y, g.z); b.mx = mk(g.w, h.x, h.y); b.slack = h.z;
+    return b;
+}
 __device__ __forceinline__ ObjHead unpack_object(float4 a, float4 b, float4 c) {
     ObjHead o;
     o.geom_kind = __float_as_uint(a.x); o.geom_index = __float_as_uint(a.y); o.material = __float_as_uint(a.z); o.xf_kind = __float_as_uint(a.w);
@@ -308,18 +322,20 @@ struct GlobalTab {
     const DevScene* S;
     __device__ __forceinline__ ObjHead object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1], p[2]); }
     __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_xf(p[3], p[4], p[5]); }
+    __device__ __forceinline__ ObjBox object_box(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_box(p[6], p[7]); }
     __device__ __forceinline__ OpRec op(uint32_t i) const { const float4* p = (const float4*)(S->ops + i); return unpack_op(p[0], p[1], p[2]); }
     __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { const float4* p = (const float4*)(S->cuboids + i); return unpack_cuboid(p[0], p[1], p[2]); }
     __device__ __forceinline__ DevRootItem root(uint32_t i) const { return S->root[i]; }
 };
 struct LdsTab {
     static constexpr bool small_scene = true;   // the tables fit the LDS budget
-    lds_float4* objects;  // 6 per object
+    lds_float4* objects;  // 8 per object
     lds_float4* ops;      // 3 per op
     lds_float4* cuboids;  // 3 per cuboid
     __attribute__((address_space(3))) const uint32_t* roots;  // kind, index pairs
-    __device__ __forceinline__ ObjHead object(uint32_t i) const { return unpack_object(lds_load4(objects + 6 * i), lds_load4(objects + 6 * i + 1), lds_load4(objects + 6 * i + 2)); }
-    __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { return unpack_xf(lds_load4(objects + 6 * i + 3), lds_load4(objects + 6 * i + 4), lds_load4(objects + 6 * i + 5)); }
+    __device__ __forceinline__ ObjHead object(uint32_t i) const { return unpack_object(lds_load4(objects + 8 * i), lds_load4(objects + 8 * i + 1), lds_load4(objects + 8 * i + 2)); }
+    __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { return unpack_xf(lds_load4(objects + 8 * i + 3), lds_load4(objects + 8 * i + 4), lds_load4(objects + 8 * i + 5)); }
+    __device__ __forceinline__ ObjBox object_box(uint32_t i) const { return unpack_box(lds_load4(objects + 8 * i + 6), lds_load4(objects + 8 * i + 7)); }
     __device__ __forceinline__ OpRec op(uint32_t i) const { return unpack_op(lds_load4(ops + 3 * i), lds_load4(ops + 3 * i + 1), lds_load4(ops + 3 * i + 2)); }
     __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { return unpack_cuboid(lds_load4(cuboids + 3 * i), lds_load4(cuboids + 3 * i + 1), lds_load4(cuboids + 3 * i + 2)); }
     __device__ __forceinline__ DevRootItem root(uint32_t i) const { return DevRootItem{roots[2 * i], roots[2 * i + 1]}; }

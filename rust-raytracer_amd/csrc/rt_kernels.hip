@@ -82,7 +82,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene S, RayBatch 
 // Scheduler versions of the two batch kernels (see rt_sched.h).
 // Stages the LDS-resident parts of the scene for a scheduler kernel: the small mesh (MESHLOC != GLOBAL)
 // followed by the scene tables (TAB_LDS).  LDS layout, in float4 units:
-//   [mesh nodes | mesh triangles | objects (2 each) | ops (3 each) | cuboids (3 each) | root items (uint2)]
+//   [mesh nodes | mesh triangles | objects (8 each) | ops (3 each) | cuboids (3 each) | root items (uint2)]
 template <int MESHLOC, bool TAB_LDS>
 __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, LdsTab& ltab) {
     uint32_t base = 0;  // float4 offset
@@ -100,7 +100,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         base = n_mesh4;
     }
     if (TAB_LDS) {
-        const uint32_t n_obj4 = 6 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
+        const uint32_t n_obj4 = 8 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
         const float4* go = (const float4*)S.objects;
         const float4* gp = (const float4*)S.ops;
         const float4* gc = (const float4*)S.cuboids;

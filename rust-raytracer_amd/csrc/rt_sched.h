@@ -406,7 +406,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                             else {
                                 const DevTree tr = S.trees[it.index];
                                 t_base = tr.node_base; t_n = tr.n_nodes; t_first = tr.first_object; t_i = 0;
-                                winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // bvh.rs:220
+                                if (!S.any_box) winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // bvh.rs:220
                                 if (t_n > 0) { fl |= F_INTREE; st = ST_TNODE; }
                             }
                         }
@@ -417,7 +417,18 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 // (3) enter the next object
                 if (st == ST_OBJ && o_cur < o_end) {
                     oi = o_cur++;
+                    // the object's box in the space of the ray: most rays miss most objects, and this test needs neither
+                    // the wrappers nor a reciprocal direction per object.  It only ever skips what the object's own first
+                    // test would turn away (the comparisons are false for NaN, so nothing is skipped on one).
                     ObjHead ob = tab.object(oi);
+                    bool skip = false;
+                    if (ob.xf_kind & XF_BOX) {
+                        const ObjBox ox = tab.object_box(oi);
+                        float bt0, bt1;
+                        box_roots(wpos, winv, ox.mn, ox.mx, bt0, bt1);
+                        skip = (bt0 > bt1) || (bt0 > wtmax * 1.00001f + ox.slack) || (bt1 < -ox.slack);
+                    }
+                    if (!skip) {
                     const ObjXf xf = tab.object_xf(oi);   // read with the head: one LDS round trip instead of two
                     opos = wpos; otmax = wtmax;
                     odir = wdir;
@@ -454,6 +465,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                             }
                         }
                     }
+                    }
                 }
             }
           }
@@ -486,6 +498,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 bool any;
                 ridx = sg_base + sg_pos + rank;
                 io.decode(ridx, raw, wpos, wdir, wtmax, any, rtag);
+                if (S.any_box) winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);
                 best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
                 // a root list that is one run of objects is walked as a range (no list reads)
                 const bool run = S.root_first != MISS;
