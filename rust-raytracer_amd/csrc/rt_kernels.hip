@@ -718,8 +718,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs
                         f3 sd, ill;
                         float tm;
                         light_sample(lt, p, nrm, rng, sd, tm, ill);
+                        // What the resolve stage cannot rebuild from the light alone: nothing for an ambient or an occlusion
+                        // light (their t_max and illumination are constants of the light), the cosine for a direction light.
                         float* q = T.smp + (size_t)s * 4 * cap + lq;
-                        q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z;
+                        if (lt.kind == LIGHT_POINT) { q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z; }
+                        else if (lt.kind == LIGHT_DIRECTION) q[0] = rust_max(dot(sd, nrm), 0.0f);   // the factor c of light.rs:120-122
                         // A sample with t_max = 0 of a light that can shoot (a point light at distance exactly 0) is queued
                         // as a zero-length ray, which nothing occludes; the resolve stage takes it as visible either way.
                         if (shoots) {
@@ -792,8 +795,13 @@ __global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, Sh
             f3 total = fill(0.0f);
             for (int k = 0; k < ns; k++, s++) {
                 const float* q = T.smp + (size_t)s * 4 * cap + j;
-                float tm = q[0];
-                f3 ill = mk(q[cap], q[2 * (size_t)cap], q[3 * (size_t)cap]);
+                const f3 E = mk(lt.emission[0], lt.emission[1], lt.emission[2]);
+                float tm;
+                f3 ill;
+                if (lt.kind == LIGHT_POINT) { tm = q[0]; ill = mk(q[cap], q[2 * (size_t)cap], q[3 * (size_t)cap]); }
+                else if (lt.kind == LIGHT_DIRECTION) { tm = 1e12f; ill = E * q[0]; }          // light.rs:120-122
+                else if (lt.kind == LIGHT_AO) { tm = lt.param; ill = E; }                    // light.rs:157
+                else { tm = 0.0f; ill = E; }                                                 // light.rs:24-27
                 bool visible = (tm == 0.0f) || (T.vis[(size_t)s * cap + j] == 0);   // integrator.rs:124
                 if (visible) total = total + ill;
             }
