@@ -167,19 +167,37 @@ def main():
     roofline = None
     cpu = None
     extra = {}
-    if rank == 0 and world == 1:
+    if rank == 0:
         scene.set_option(rt.OPT_PROFILE, 1)
         scene.kernel_times(reset=True)
         _, st = scene.render(max_depth=max_depth, shadow_rays=shadow_rays, antialiasing=aa, region=region, out_device=tiles)
         kt = scene.kernel_times(reset=True)
         scene.set_option(rt.OPT_PROFILE, 0)
         cnt = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cpu, cnt = cpu_baseline(sky, cam_wh, aa, max_depth, shadow_rays)
-        if cnt is not None and kt["closest_launches"]:
+        # algorithmic bytes per ray of this workload: from the oracle's visit counters when the CPU leg ran (and kept
+        # in profiles/byte_model.json), else the kept values (N > 1 ranks trace the same scene with the same mix of rays)
+        mpath = os.path.join(ROOT, "profiles", "byte_model.json")
+        model = None
+        if cnt is not None:
+            model = byte_model(cnt)
+            try:
+                kept = json.load(open(mpath)) if os.path.exists(mpath) else {}
+                kept[args.workload] = {"closest": model[0], "any": model[1]}
+                json.dump(kept, open(mpath, "w"), indent=1)
+            except Exception:
+                pass
+        elif os.path.exists(mpath):
+            try:
+                m = json.load(open(mpath)).get(args.workload)
+                model = (m["closest"], m["any"]) if m else None
+            except Exception:
+                model = None
+        if model is not None and kt["closest_launches"]:
             # k_wave_trace carries the closest-hit rays of a bounce plus the shadow rays of the previous one; the
             # launch that ends a sample carries shadow rays only.  All its launches are pooled.
-            b_closest, b_any = byte_model(cnt)
+            b_closest, b_any = model
             n_launch = kt["closest_launches"] + kt["any_launches"]
             trace_ms = kt["closest_ms"] + kt["any_ms"]
             avg_ms = trace_ms / n_launch
