@@ -50,6 +50,10 @@ static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
 #define RTAMD_OBJ_STAY_NUM 3
 #endif
 static constexpr uint32_t OBJ_STAY_NUM = RTAMD_OBJ_STAY_NUM;
+#ifndef RTAMD_TNODE_STAY_NUM
+#define RTAMD_TNODE_STAY_NUM 3
+#endif
+static constexpr uint32_t TNODE_STAY_NUM = RTAMD_TNODE_STAY_NUM;
 static constexpr uint32_t NODE_STAY_NUM = RTAMD_NODE_STAY_NUM, NODE_STAY_DEN = RTAMD_NODE_STAY_DEN;
 // Vote weights (TRI, NODE, OBJ, FETCH, TNODE): a phase's lane count is multiplied by its weight before the
 // comparison, so a phase with a low weight waits until it has gathered proportionally more lanes.  The OBJ and
@@ -360,7 +364,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             if (st == ST_NODE) node_step();
           }
         } else if (phase == ST_TNODE) {
-          for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * STAY_NUM && c > 0; c = wave_count(st == ST_TNODE)) {
+          for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * TNODE_STAY_NUM && c > 0; c = wave_count(st == ST_TNODE)) {
             DIAG_STEP(ST_TNODE, c)
             if (st == ST_TNODE) {
                 const float4* np = S.nodes + 2 * ((size_t)t_base + t_i);
