@@ -475,6 +475,15 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         uint32_t last = 0;
         for (uint32_t k = 0; k < ob.op_count && d.xf_kind != XF_GENERIC; k++) {
             const rtamd_xform_op& op = sc->ops[ob.op_first + k];
+            // A Translate by (+0, +0, +0) leaves every ray position as it is, bit for bit (x - (+0) == x, also for -0, inf
+            // and NaN): the reference's Transform always carries one (transform.rs:224-230), often with a zero offset
+            // under another Translate.  It takes no part in entering the object; the hit is still carried out through
+            // the full op list.
+            if (op.kind == RTAMD_OP_TRANSLATE) {
+                uint32_t bits[3];
+                std::memcpy(bits, op.v, 12);
+                if ((bits[0] | bits[1] | bits[2]) == 0u) continue;
+            }
             const uint32_t bit = op.kind == RTAMD_OP_TRANSLATE ? XF_T : op.kind == RTAMD_OP_SCALE ? XF_S : op.kind == RTAMD_OP_ROTATE ? XF_R : XF_GENERIC;
             if (bit == XF_GENERIC || bit <= last) { d.xf_kind = XF_GENERIC; break; }
             last = bit;
