@@ -31,7 +31,7 @@ enum rtamd_error {
     RTAMD_E_INVALID = 1,   /* bad argument / inconsistent scene description */
     RTAMD_E_DEVICE = 2,    /* HIP runtime error */
     RTAMD_E_NOSCENE = 3,   /* trace/render before a scene was uploaded */
-    RTAMD_E_UNSUPPORTED = 4
+    RTAMD_E_UNSUPPORTED = 4 /* a valid request beyond a fixed limit of the device code (max_depth above 64) */
 };
 
 typedef struct rtamd_context rtamd_context;
@@ -146,7 +146,7 @@ typedef struct rtamd_image {
 
 /* Lights: replaces the Light impls of src/light.rs:12-158.  emission = color * intensity.
  *   AMBIENT; DIRECTION(vec = normalised direction, param = spread, <= 0: none);
- *   AO(param = distance); POINT(vec = position, param = radius; not yet supported on the device). */
+ *   AO(param = distance); POINT(vec = position, param = radius of the emitting ball, 0 = a true point). */
 enum rtamd_light_kind { RTAMD_LIGHT_AMBIENT = 0, RTAMD_LIGHT_POINT = 1, RTAMD_LIGHT_DIRECTION = 2, RTAMD_LIGHT_AO = 3 };
 typedef struct rtamd_light {
     uint32_t kind;
@@ -250,6 +250,17 @@ int rtamd_trace_any(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_
  * (a hipStream_t, NULL = the context's own stream, in which case the call blocks until done). */
 int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream);
 int rtamd_trace_any_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out, void* stream);
+
+/* rtamd_trace_closest_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The call allocates and frees nothing and never
+ * synchronises with the host when `stream` is given: the only device memory it uses beyond `rays` and `out` is one
+ * queue-head word taken in turn from a ring of 64 words in a static array of the library's own image (256 bytes,
+ * held by every GPU the library runs on until the process ends), zeroed on the stream right before the kernel.
+ * Limits: n <= RTAMD_STATIC_MAX_RAYS (RTAMD_E_INVALID beyond it); the ring is shared by all contexts of one GPU, so at
+ * most 64 such calls may be in flight on one GPU at a time -- a 65th that overlaps the first races with it on its
+ * head word.  Results are those of rtamd_trace_closest_device, bit for bit. */
+#define RTAMD_STATIC_MAX_RAYS 0x7FFFFFFFull
+int rtamd_trace_closest_static(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream);
 
 /* Number of floats-triples rtamd_render writes for a region (owned tiles x tile_w x tile_h). */
 size_t rtamd_region_pixels(const rtamd_region* region);

@@ -67,7 +67,7 @@ class Stats(C.Structure):  # rtamd_stats
 ABI_SYMBOLS = (
     "rtamd_create", "rtamd_destroy", "rtamd_last_error", "rtamd_upload_scene", "rtamd_trace_closest", "rtamd_trace_any",
     "rtamd_trace_closest_device", "rtamd_trace_any_device", "rtamd_region_pixels", "rtamd_render", "rtamd_render_device",
-    "rtamd_quantize_device", "rtamd_set_option", "rtamd_kernel_times",
+    "rtamd_quantize_device", "rtamd_set_option", "rtamd_kernel_times", "rtamd_trace_closest_static",
 )
 
 
@@ -97,6 +97,7 @@ def rtamd_lib():
         _rt.rtamd_trace_any.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_void_p]
         _rt.rtamd_trace_closest_device.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits), C.c_void_p]
         _rt.rtamd_trace_any_device.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.c_void_p, C.c_void_p]
+        _rt.rtamd_trace_closest_static.argtypes = [C.c_void_p, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits), C.c_void_p]
         _rt.rtamd_region_pixels.restype = C.c_size_t
         _rt.rtamd_region_pixels.argtypes = [C.POINTER(Region)]
         _rt.rtamd_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Integrator), C.POINTER(Region), C.c_void_p, C.POINTER(Stats)]
@@ -277,6 +278,13 @@ class Scene:
         r = Rays(*[_ptr(a) for a in rays])
         h = Hits(*[_ptr(a) for a in hits])
         self._check(rtamd_lib().rtamd_trace_closest_device(self.ctx, C.byref(r), n, C.byref(h), stream), "rtamd_trace_closest_device")
+
+    def trace_closest_static(self, rays, hits, n, stream=None):
+        """trace_closest_device through the entry point that allocates nothing (queue head in the library's static array)."""
+        self._need_ctx()
+        r = Rays(*[_ptr(a) for a in rays])
+        h = Hits(*[_ptr(a) for a in hits])
+        self._check(rtamd_lib().rtamd_trace_closest_static(self.ctx, C.byref(r), n, C.byref(h), stream), "rtamd_trace_closest_static")
 
     def trace_any_device(self, rays, out, n, stream=None):
         self._need_ctx()

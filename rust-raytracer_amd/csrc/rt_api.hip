@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,7 +48,10 @@ struct rtamd_context {
     // ray batch workspace of the host-pointer entry points
     void* batch_buf = nullptr;
     size_t batch_bytes = 0;
-    uint32_t* work_head = nullptr;   // queue head of the batch trace kernels
+    // Queue heads of the batch trace kernels: a ring of HEAD_RING words, one per call in turn, so that calls in flight
+    // on different streams of the caller do not share a head.
+    uint32_t* work_head = nullptr;
+    uint32_t head_next = 0;
 
     // kernel timing (RTAMD_OPT_PROFILE)
     double closest_ms = 0, any_ms = 0, shade_ms = 0;
@@ -57,7 +61,18 @@ struct rtamd_context {
     std::vector<hipEvent_t> event_pool;
 };
 
+// Queue heads of rtamd_trace_closest_static, the entry point that allocates nothing: a ring of HEAD_RING words in the
+// library's own image.  Every GPU the library runs on holds its own copy at its own address; the name below is only a
+// host-side handle for hipGetSymbolAddress, host code uses the per-device pointers in g_scratch_ptr.
+static constexpr uint32_t HEAD_RING = 64;
+static __device__ __align__(256) uint32_t scratch[HEAD_RING];
+
 namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+uint32_t* g_scratch_ptr[MAX_DEVICES] = {};   // device address of `scratch` on each GPU, set by rtamd_create
+uint32_t g_scratch_next[MAX_DEVICES] = {};   // next ring slot per GPU
 
 int fail(rtamd_context* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
@@ -326,10 +341,23 @@ int rtamd_create(int device_id, rtamd_context** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->cfg.num_cus = prop.multiProcessorCount;
-    if (hipMalloc((void**)&ctx->work_head, 256) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->work_head, HEAD_RING * sizeof(uint32_t)) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return RTAMD_E_DEVICE;
+    }
+    {   // this GPU's address of the static scratch array (once per device, with the device current)
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (device_id < MAX_DEVICES && g_scratch_ptr[device_id] == nullptr) {
+            void* p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || p == nullptr) {
+                (void)hipFree(ctx->work_head);
+                (void)hipStreamDestroy(ctx->stream);
+                delete ctx;
+                return RTAMD_E_DEVICE;
+            }
+            g_scratch_ptr[device_id] = (uint32_t*)p;
+        }
     }
     *out = ctx;
     return RTAMD_OK;
@@ -623,9 +651,11 @@ int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
     HitBatch hb{out->obj, out->prim, out->t, out->u, out->v};
-    timed_begin(ctx, 0, st);
-    HIP_TRY(ctx, launch_trace_closest(ctx->S, ctx->cfg, rb, hb, n, ctx->work_head, st));
-    timed_end(ctx, st);
+    uint32_t* head = ctx->work_head + (ctx->head_next++ % HEAD_RING);
+    // kernel timing only on the context's own stream, where the events are collected right after the call
+    if (!stream) timed_begin(ctx, 0, st);
+    HIP_TRY(ctx, launch_trace_closest(ctx->S, ctx->cfg, rb, hb, n, head, st));
+    if (!stream) timed_end(ctx, st);
     if (!stream) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
         timed_collect(ctx, nullptr);
@@ -640,13 +670,41 @@ int rtamd_trace_any_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
-    timed_begin(ctx, 1, st);
-    HIP_TRY(ctx, launch_trace_any(ctx->S, ctx->cfg, rb, out, n, ctx->work_head, st));
-    timed_end(ctx, st);
+    uint32_t* head = ctx->work_head + (ctx->head_next++ % HEAD_RING);
+    if (!stream) timed_begin(ctx, 1, st);
+    HIP_TRY(ctx, launch_trace_any(ctx->S, ctx->cfg, rb, out, n, head, st));
+    if (!stream) timed_end(ctx, st);
     if (!stream) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
         timed_collect(ctx, nullptr);
     }
+    return RTAMD_OK;
+}
+
+// The variant of rtamd_trace_closest_device that allocates nothing: the scheduler kernel's queue head lives in the
+// static `scratch` array of this GPU instead of the context's heap allocation.  No hipMalloc / hipFree, no host
+// synchronisation: one 4-byte hipMemsetAsync and one kernel launch on the caller's stream.
+int rtamd_trace_closest_static(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream) {
+    if (!ctx || !rays || !out) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NOSCENE, "no scene uploaded");
+    if (n > RTAMD_STATIC_MAX_RAYS) return fail(ctx, RTAMD_E_INVALID, "rtamd_trace_closest_static: at most RTAMD_STATIC_MAX_RAYS (2^31-1) rays per call");
+    if (n == 0) return RTAMD_OK;
+    if (ctx->device < 0 || ctx->device >= MAX_DEVICES) return fail(ctx, RTAMD_E_INVALID, "rtamd_trace_closest_static: device index beyond the library's table");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t* head;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        uint32_t* base = g_scratch_ptr[ctx->device];
+        if (!base) return fail(ctx, RTAMD_E_DEVICE, "rtamd_trace_closest_static: the scratch array of this GPU was not resolved");
+        head = base + (g_scratch_next[ctx->device]++ % HEAD_RING);
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
+    HitBatch hb{out->obj, out->prim, out->t, out->u, out->v};
+    LaunchCfg cfg = ctx->cfg;
+    cfg.scheduler = 1;   // the kernel that uses the scratch word
+    HIP_TRY(ctx, launch_trace_closest(ctx->S, cfg, rb, hb, n, head, st));   // zeroes its head word on `st` first
+    if (!stream) HIP_TRY(ctx, hipStreamSynchronize(st));
     return RTAMD_OK;
 }
 
@@ -758,7 +816,7 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
         return fail(ctx, RTAMD_E_INVALID, "region exceeds the camera image");
     if (integ->antialiasing < 1) return fail(ctx, RTAMD_E_INVALID, "antialiasing must be >= 1");
     if (integ->shadow_rays < 1) return fail(ctx, RTAMD_E_INVALID, "shadow_rays must be >= 1");
-    if (integ->max_depth > (int)CounterSlots::MAX_DEPTH) return fail(ctx, RTAMD_E_INVALID, "max_depth above 64 is not supported");
+    if (integ->max_depth > (int)CounterSlots::MAX_DEPTH) return fail(ctx, RTAMD_E_UNSUPPORTED, "max_depth above 64 is not supported");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     uint32_t S_total = 0;
