@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the render hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-Workload (BASELINE.json configs[2], the one the metric "primary + diffuse bounce" is quoted on): the reference's
-bunny scene (3 instanced bunnies + glossy floor + real skybox) at 1080x960, antialiasing 8 (64 spp),
-max_depth 5, shadow_rays 1, scatter_rays 1.  One step = one full frame through the wavefront kernels
-(ray generation, closest-hit trace, shade, shadow trace, compaction), scene and skybox resident in HBM.
+Default workload (BASELINE.json configs[2], the one the metric "primary + diffuse bounce" is quoted on): the reference's
+bunny scene (3 instanced bunnies + glossy floor + the real skybox) at 1080x960, antialiasing 8 (64 spp), max_depth 5,
+shadow_rays 1, scatter_rays 1.  One step = one full frame through the wavefront kernels (ray generation, closest-hit
+trace, shade, shadow trace, compaction), scene and skybox resident in HBM.
 Metric: Mrays/s = (closest-hit + any-hit rays traced) / wall time, whole job.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame grows with N at the same camera, aspect
-ratio and samples per pixel (N x 1080x960 pixels: 1528x1358, 2160x1920, 3056x2715 for N = 2, 4, 8), its 64x64 tiles
-are dealt round-robin to the ranks, every rank renders its tiles, and the framebuffer is gathered to rank 0 with
-one RCCL gather inside the timed region.  Per-GPU work is fixed, so this is weak scaling: a 1080x960 frame cut in
-eight leaves each GPU launches of a few ten thousand rays, which measure launch latency rather than the path.
+Other workloads: the 4K primary-ray batch (configs[1]), 10 000 spheres in an object tree at 3840x2160 / 64 spp
+(configs[3]) and the 230 x 230 instanced-bunny grid (50.1 M triangles) at 7680x4320 / 256 spp (configs[4]).
+
+N > 1: the SAME frame is cut into 64x64 tiles that are dealt round-robin to the ranks (one rank per GPU, scene
+replicated), every rank renders its tiles and the framebuffer is gathered to rank 0 with one RCCL gather inside the
+timed region: total work is fixed, i.e. strong scaling.  `--weak` grows the frame with N instead (N x the pixels at
+the same camera and aspect ratio) and says so in `config`.  `python bench.py --gpus N` from a plain shell starts its
+own N ranks (torch.distributed.run, 127.0.0.1) before anything touches the GPU; under torch.distributed.run it is one
+of the ranks.  On a box with fewer GPUs than ranks the ranks share devices and gather through gloo (a rehearsal).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,13 +37,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
+# name: scene constructor, camera, antialiasing, max_depth, shadow_rays, BASELINE.json configs[] index
 WORKLOADS = {
-    # name: (camera, antialiasing, max_depth, shadow_rays)
-    "bunny_1080x960_64spp_depth5": ((1080, 960), 8, 5, 1),
-    "bunny_3840x2160_primary": ((3840, 2160), 1, 1, 1),
+    "bunny_1080x960_64spp_depth5": dict(scene=("main",), cam=(1080, 960), aa=8, max_depth=5, shadow_rays=1, baseline_config=2,
+                                        desc="reference main.rs scene: bundled bunny.ply x3 instances + floor cuboid + skybox.jpg"),
+    "bunny_3840x2160_primary": dict(scene=("main",), cam=(3840, 2160), aa=1, max_depth=1, shadow_rays=1, baseline_config=1,
+                                    desc="reference main.rs scene, primary rays and their shadow rays only"),
+    "spheres_10k_3840x2160_64spp_depth5": dict(scene=("spheres", 10000, 1), cam=(3840, 2160), aa=8, max_depth=5, shadow_rays=1, baseline_config=3,
+                                               desc="10 000 spheres (splitmix64 seed 1) in one AABBTree<Object> over a floor cuboid + skybox.jpg"),
+    "bunny_grid_230x230_7680x4320_256spp_depth5": dict(scene=("grid", 230, 230), cam=(7680, 4320), aa=16, max_depth=5, shadow_rays=1, baseline_config=4,
+                                                       desc="230 x 230 instances of the bundled bunny (50.1 M triangles) in one AABBTree<Object>, instanced (one mesh tree, "
+                                                            "per-instance ray transform) + floor cuboid + skybox.jpg"),
+    "bunny_grid_flat_230x230_7680x4320_256spp_depth5": dict(scene=("grid_flat", 230, 230), cam=(7680, 4320), aa=16, max_depth=5, shadow_rays=1, baseline_config=4,
+                                                            desc="the same 230 x 230 grid flattened to world space: 52 900 separate meshes (50.1 M world-space triangles, "
+                                                                 "one tree each) in one AABBTree<Object> + floor cuboid + skybox.jpg"),
 }
+DEFAULT_WORKLOAD = "bunny_1080x960_64spp_depth5"
 TILE = 64
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
+N_SIMD = 1024                    # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4
+VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0   # one wave64 VALU instruction per SIMD every 2 cycles: 1228.8 G wave-instructions/s
+TRACE_KERNEL = "k_wave_trace"
 
 
 def cpu_threads():
@@ -44,34 +69,108 @@ def cpu_threads():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(sky, cam, aa, max_depth, shadow_rays):
-    """Times the CPU oracle (C++ restatement of the reference renderer) on a bounded sample of the workload and
-    returns its throughput plus the reference-order visit counters used for the algorithmic byte model."""
+def make_scene(mod, spec, sky, cam):
+    kind = spec[0]
+    if kind == "main":
+        return mod.main(sky=sky, cam=cam)
+    if kind == "spheres":
+        return mod.spheres(n=spec[1], seed=spec[2], sky=sky, cam=cam)
+    if kind == "grid":
+        return mod.grid(spec[1], spec[2], sky=sky, cam=cam)
+    if kind == "grid_flat":
+        return mod.grid(spec[1], spec[2], sky=sky, cam=cam, flat=True)
+    raise SystemExit(f"unknown scene {spec}")
+
+
+def cpu_baseline(wl, sky, cam, aa):
+    """Times the CPU oracle (C++ restatement of the reference renderer) on a bounded sample of the workload and returns
+    its throughput plus the reference-order visit counters used for the algorithmic byte model."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    scene = ol.OracleScene.main(sky=sky, cam=cam)
-    sample_aa = max(1, aa // 2)  # same frame, scene, depth and lights at a quarter of the samples per pixel
+    scene = make_scene(ol.OracleScene, wl["scene"], sky, cam)
     threads = cpu_threads()
-    _, sec, cnt = scene.render(max_depth=max_depth, shadow_rays=shadow_rays, antialiasing=sample_aa, threads=threads)
+    # bounded sample: a centred rectangle of at most 1080 x 960 pixels at a sample count that gives about 50 M paths
+    # (10 - 30 s on 16 host cores), never more than the workload's own
+    rw, rh = min(cam[0], 1080), min(cam[1], 960)
+    rect = ((cam[0] - rw) // 2, (cam[1] - rh) // 2, rw, rh)
+    sample_aa = max(1, min(aa, int((50e6 / (rw * rh)) ** 0.5)))
+    _, sec, cnt = scene.render(max_depth=wl["max_depth"], shadow_rays=wl["shadow_rays"], antialiasing=sample_aa, rect=rect, threads=threads)
     rays = cnt["closest_rays"] + cnt["any_rays"]
     base = {
         "value": rays / sec / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"full {cam[0]}x{cam[1]} frame at antialiasing {sample_aa} ({sample_aa * sample_aa} spp) instead of {aa * aa} spp, "
-                  f"{rays} rays in {sec:.2f} s, 100-pixel chunks over {threads} threads",
+        "sample": f"centred {rw}x{rh} rectangle of the {cam[0]}x{cam[1]} frame at antialiasing {sample_aa} ({sample_aa * sample_aa} spp) instead of "
+                  f"{aa * aa} spp, same scene, depth and lights: {rays} rays in {sec:.2f} s, 100-pixel chunks over {threads} threads",
     }
     return base, cnt
 
 
 def byte_model(cnt):
     """Algorithmic bytes per ray from the oracle's reference-order visit counters:
-    closest ray: 32 B in + 16 B out + 32 B per node visited + 36 B per triangle tested + 36 B per cuboid test;
-    any-hit ray: 32 B in + 4 B out + the same traversal terms."""
+    closest ray: 32 B in + 16 B out + 32 B per node visited + 36 B per triangle tested + 16 B per sphere + 36 B per cuboid
+    test; any-hit ray: 32 B in + 4 B out + the same traversal terms."""
     nc = cnt["nodes_visited"] - cnt["nodes_visited_any"]
     tc = cnt["tris_tested"] - cnt["tris_tested_any"]
+    sc = cnt["spheres_tested"] - cnt["spheres_tested_any"]
     cc = cnt["cuboids_tested"] - cnt["cuboids_tested_any"]
-    closest = 48.0 + (32.0 * nc + 36.0 * tc + 36.0 * cc) / max(1, cnt["closest_rays"])
-    anyb = 36.0 + (32.0 * cnt["nodes_visited_any"] + 36.0 * cnt["tris_tested_any"] + 36.0 * cnt["cuboids_tested_any"]) / max(1, cnt["any_rays"])
+    closest = 48.0 + (32.0 * nc + 36.0 * tc + 16.0 * sc + 36.0 * cc) / max(1, cnt["closest_rays"])
+    anyb = 36.0 + (32.0 * cnt["nodes_visited_any"] + 36.0 * cnt["tris_tested_any"] + 16.0 * cnt["spheres_tested_any"]
+                   + 36.0 * cnt["cuboids_tested_any"]) / max(1, cnt["any_rays"])
     return closest, anyb
+
+
+# ---- counter passes: this program again, as a child of rocprofv3, one --pmc pass per run ----------------------------
+PMC_PASSES = (
+    ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY"]),
+    ("fetch", ["FETCH_SIZE", "TCC_HIT_sum"]),
+    ("write", ["WRITE_SIZE", "TCC_MISS_sum"]),
+)
+
+
+def run_pmc_passes(argv_inner, timeout_s=150):
+    """Returns {counter: (sum over the trace kernel's dispatches, dispatches)} or None when rocprofv3 is unavailable."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for name, counters in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix=f"rtamd_pmc_{name}_", dir="/tmp")
+        cmd = ["timeout", "-s", "KILL", str(timeout_s), exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.abspath(__file__), "--inner"] + argv_inner
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s + 30)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            seen = {}
+            for r in csv.DictReader(open(files[0])):
+                if TRACE_KERNEL in r["Kernel_Name"]:
+                    s, disp = seen.setdefault(r["Counter_Name"], [0.0, set()])
+                    seen[r["Counter_Name"]][0] = s + float(r["Counter_Value"])
+                    disp.add(r["Dispatch_Id"])
+            for k, (s, disp) in seen.items():
+                out[k] = (s, len(disp))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out or None
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell: start N ranks as children.  Nothing here touches the GPU."""
+    import torch
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < n:   # counting devices does not initialise the GPU
+        env.setdefault("RTAMD_BENCH_BACKEND", "gloo")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -79,11 +178,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="bunny_1080x960_64spp_depth5", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--aa", type=int, default=0, help="override the workload's antialiasing (spp = aa^2); recorded in config")
+    ap.add_argument("--cam", default="", help="override the workload's frame, WxH; recorded in config")
+    ap.add_argument("--weak", action="store_true", help="N > 1: grow the frame with N (fixed work per GPU) instead of splitting one frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and the VALU count stay null)")
     ap.add_argument("--small-sky", action="store_true", help="use a strided skybox (debug)")
     ap.add_argument("--opt", default="", help="tuning overrides, e.g. chunk=128,blocks=3,lds=0,max_paths=2097152")
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # child of a rocprofv3 counter pass: render only
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -92,8 +199,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the render path)")
     # RTAMD_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
@@ -112,13 +218,21 @@ def main():
     rt = entry.load_package()
     from rust_raytracer_amd import dist_tiles
 
-    cam_wh, aa, max_depth, shadow_rays = WORKLOADS[args.workload]
-    base_wh = cam_wh
-    if world > 1:  # weak scaling: world x the pixels, same aspect ratio
-        w = int(round(cam_wh[0] * (world ** 0.5) / 8.0)) * 8
-        cam_wh = (w, int(round(world * cam_wh[0] * cam_wh[1] / w)))
+    wl = WORKLOADS[args.workload]
+    aa = args.aa or wl["aa"]
+    max_depth, shadow_rays = wl["max_depth"], wl["shadow_rays"]
+    base_wh = tuple(int(v) for v in args.cam.split("x")) if args.cam else wl["cam"]
+    cam_wh = base_wh
+    if world > 1 and args.weak:  # weak scaling: world x the pixels, same aspect ratio
+        w = int(round(base_wh[0] * (world ** 0.5) / 8.0)) * 8
+        cam_wh = (w, int(round(world * base_wh[0] * base_wh[1] / w)))
     sky = rt.load_skybox(max_width=1024 if args.small_sky else None)
-    scene = rt.Scene.main(sky=sky, cam=cam_wh).upload(dev_index)
+    t0 = time.perf_counter()
+    scene = make_scene(rt.Scene, wl["scene"], sky, cam_wh)
+    host_build_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    scene.upload(dev_index)
+    upload_s = time.perf_counter() - t0
     opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "max_paths": rt.OPT_MAX_PATHS, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH}
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
@@ -138,6 +252,12 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.inner:   # counter pass: the frame itself, nothing else
+        for _ in range(max(1, args.steps)):
+            step()
+        torch.cuda.synchronize()
+        return
 
     for _ in range(args.warmup):
         step()
@@ -163,7 +283,7 @@ def main():
         rays = float(t[1])
         closest_per_step, any_per_step, paths_per_step = float(t[2]), float(t[3]), float(t[4])
 
-    # ---- rank 0, N = 1: roofline of the dominant kernel (HIP events on the kernels' own stream) + CPU baseline ----
+    # ---- rank 0: bound of the dominant kernel (HIP events on the kernels' own stream), counters, CPU baseline ----
     roofline = None
     cpu = None
     extra = {}
@@ -175,68 +295,77 @@ def main():
         scene.set_option(rt.OPT_PROFILE, 0)
         cnt = None
         if not args.no_cpu_baseline and world == 1:
-            cpu, cnt = cpu_baseline(sky, cam_wh, aa, max_depth, shadow_rays)
-        # algorithmic bytes per ray of this workload: from the oracle's visit counters when the CPU leg ran (and kept
-        # in profiles/byte_model.json), else the kept values (N > 1 ranks trace the same scene with the same mix of rays)
-        mpath = os.path.join(ROOT, "profiles", "byte_model.json")
-        model = None
-        if cnt is not None:
-            model = byte_model(cnt)
-            try:
-                kept = json.load(open(mpath)) if os.path.exists(mpath) else {}
-                kept[args.workload] = {"closest": model[0], "any": model[1]}
-                json.dump(kept, open(mpath, "w"), indent=1)
-            except Exception:
-                pass
-        elif os.path.exists(mpath):
-            try:
-                m = json.load(open(mpath)).get(args.workload)
-                model = (m["closest"], m["any"]) if m else None
-            except Exception:
-                model = None
-        if model is not None and kt["closest_launches"]:
+            cpu, cnt = cpu_baseline(wl, sky, cam_wh, aa)
+        pmc = None
+        if not args.no_pmc and world == 1:
+            inner = ["--workload", args.workload, "--steps", "1", "--warmup", "0", "--aa", str(aa), "--cam", f"{W}x{H}"]
+            if args.opt:
+                inner += ["--opt", args.opt]
+            if args.small_sky:
+                inner += ["--small-sky"]
+            pmc = run_pmc_passes(inner)
+        if kt["closest_launches"] + kt["any_launches"]:
             # k_wave_trace carries the closest-hit rays of a bounce plus the shadow rays of the previous one; the
             # launch that ends a sample carries shadow rays only.  All its launches are pooled.
-            b_closest, b_any = model
             n_launch = kt["closest_launches"] + kt["any_launches"]
             trace_ms = kt["closest_ms"] + kt["any_ms"]
             avg_ms = trace_ms / n_launch
-            rays_per_launch = (st["closest_rays"] + st["any_rays"]) / n_launch
-            bytes_per_launch = (st["closest_rays"] * b_closest + st["any_rays"] * b_any) / n_launch
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("workload") == args.workload:
-                        traffic = tj.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "kernel": "k_wave_trace (persistent closest-hit + any-hit traversal of the wavefront queues)",
+            n_rays = st["closest_rays"] + st["any_rays"]
+            rays_per_launch = n_rays / n_launch
+            rays_per_s = n_rays / (trace_ms * 1e-3)
+            # The scene's nodes and triangles are served from LDS / L2, so the kernel is bound by instruction issue and
+            # LDS / L2 latency, not by HBM: `achieved` counts the VALU wave-instructions it issues per second (rocprofv3
+            # SQ_INSTS_VALU of one frame / its rays, times the live ray rate) against one instruction per SIMD per 2 cycles.
+            valu_per_ray = hbm_bytes = lane_util = l2_hit = None
+            if pmc and "SQ_INSTS_VALU" in pmc:
+                valu_per_ray = pmc["SQ_INSTS_VALU"][0] / n_rays
+                if pmc.get("SQ_ACTIVE_INST_VALU", (0, 0))[0]:
+                    lane_util = pmc["SQ_THREAD_CYCLES_VALU"][0] / (pmc["SQ_ACTIVE_INST_VALU"][0] * 64.0)
+            if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # KiB; gfx950 tallies a 128-byte read request at 64 bytes: the read side is doubled (an upper bound for narrow reads)
+                hbm_bytes = (2.0 * pmc["FETCH_SIZE"][0] * 1024.0 / pmc["FETCH_SIZE"][1]) + (pmc["WRITE_SIZE"][0] * 1024.0 / pmc["WRITE_SIZE"][1])
+            if pmc and "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
+                l2_hit = pmc["TCC_HIT_sum"][0] / max(1.0, pmc["TCC_HIT_sum"][0] + pmc["TCC_MISS_sum"][0])
+            achieved = valu_per_ray * rays_per_s / 1e9 if valu_per_ray else None
+            roofline = {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
+                        "frac": achieved / VALU_PEAK_GINST if achieved else None, "traffic": hbm_bytes,
+                        "kernel": "k_wave_trace (persistent closest-hit + any-hit traversal of the wavefront queues)",
                         "avg_launch_ms": avg_ms, "launches": n_launch, "rays_per_launch": rays_per_launch,
-                        "algorithmic_bytes_per_closest_ray": b_closest, "algorithmic_bytes_per_any_ray": b_any,
+                        "valu_wave_insts_per_ray": valu_per_ray, "valu_lane_utilisation": lane_util,
+                        "note": "bound = vector-instruction issue + LDS/L2 latency (tree and triangles are LDS- or L2-resident); "
+                                "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; hbm_* = measured HBM traffic of the same "
+                                "kernel against the 8 TB/s peak; algorithmic_* = the reference-order byte model, mostly served from LDS/L2",
+                        "hbm_gbs": hbm_bytes / (avg_ms * 1e-3) / 1e9 if hbm_bytes else None,
+                        "hbm_frac": hbm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if hbm_bytes else None,
+                        "l2_hit_rate": l2_hit,
                         "stream_only_gbs": (st["closest_rays"] * 48.0 + st["any_rays"] * 36.0) / (trace_ms * 1e-3) / 1e9}
-            extra["trace_kernel_mrays_per_s"] = (st["closest_rays"] + st["any_rays"]) / (trace_ms * 1e-3) / 1e6
+            if cnt is not None:
+                b_closest, b_any = byte_model(cnt)
+                alg = (st["closest_rays"] * b_closest + st["any_rays"] * b_any) / (trace_ms * 1e-3) / 1e9
+                roofline.update({"algorithmic_bytes_per_closest_ray": b_closest, "algorithmic_bytes_per_any_ray": b_any,
+                                 "algorithmic_gbs": alg, "algorithmic_frac_of_hbm_peak": alg / HBM_PEAK_GBS})
+            extra["trace_kernel_mrays_per_s"] = rays_per_s / 1e6
             extra["stage_ms_per_frame"] = {"trace": trace_ms, "shade_resolve": st["shade_ms"], "device_total": st["device_ms"]}
 
     if rank == 0:
         value = rays / elapsed / 1e6
+        reduced = (aa != wl["aa"]) or (base_wh != wl["cam"])
         line = {
             "metric": "Mrays/s (primary + diffuse bounce) on bunny BVH", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "width": W, "height": H, "spp": aa * aa, "max_depth": max_depth,
+            "higher_is_better": True, "scaling": "weak" if (world > 1 and args.weak) else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "reference assets (bunny.ply, skybox.jpg) + generated instance / sphere placement" if wl["scene"][0] != "main"
+                    else "reference assets (bunny.ply, skybox.jpg)",
+            "config": {"workload": args.workload, "baseline_config": wl["baseline_config"], "width": W, "height": H, "spp": aa * aa, "max_depth": max_depth,
                        "shadow_rays": shadow_rays, "scatter_rays": 1, "tile": TILE,
-                       "parallelism": f"tiles{world}" if world > 1 else "single",
-                       "frame_per_gpu": f"{base_wh[0]}x{base_wh[1]}",
-                       "scene": "reference main.rs scene: bundled bunny.ply x3 instances + floor cuboid + skybox.jpg"},
+                       "parallelism": (f"tiles{world} of one {W}x{H} frame" if not args.weak else f"tiles{world}, frame grown from {base_wh[0]}x{base_wh[1]} per GPU") if world > 1 else "single",
+                       "backend": ("rccl" if backend == "nccl" else backend + " (ranks share devices: rehearsal)") if world > 1 else None,
+                       "reduced_from_workload": reduced, "scene": wl["desc"], "host_build_s": host_build_s, "upload_s": upload_s},
             "rays_per_step": {"closest": closest_per_step, "any": any_per_step, "paths": paths_per_step},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

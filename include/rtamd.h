@@ -275,6 +275,18 @@ int rtamd_render(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integr
 int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ,
                         const rtamd_region* region, float* out_rgb_device, rtamd_stats* stats);
 
+/* render::parallel_render (src/render.rs:10-56) of one frame over several GPUs, the form `render.rs` would call on a
+ * multi-GPU node: the rectangle (x0, y0, w, h) of the camera image is cut into tile_w x tile_h tiles that are dealt
+ * round-robin to the n contexts (normally one per GPU; several contexts on one GPU work too), each context renders
+ * its tiles on a host thread of its own, and the tiles land row-major in out_rgb (w*h*3 floats, host memory).  Every
+ * context must hold the same uploaded scene.  Pixels are identical to a single-context render: a pixel's random stream
+ * depends only on its coordinates (src/integrator.rs:36).  stats: ray, path and launch counts summed over the
+ * contexts, the *_ms fields the maximum.  On failure the code of the first failing context is returned and its message
+ * is readable from that context (and from ctxs[0]). */
+int rtamd_render_multi(rtamd_context* const* ctxs, int n, const rtamd_camera* cam, const rtamd_integrator* integ,
+                       uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h,
+                       float* out_rgb, rtamd_stats* stats);
+
 /* render::parallel_render_image quantiser (src/render.rs:62-72): floor(c*256) clamped to [0,255],
  * on device memory, n = number of floats. */
 int rtamd_quantize_device(rtamd_context* ctx, const float* rgb_device, size_t n, uint8_t* out_device);

@@ -71,6 +71,21 @@ Mat3 Mat3::new_rotation(V3 axis, float angle) {  // mat3d.rs:47-64
     r.m[2][2] = c + z * z * (1.0f - c);
     return r;
 }
+Mat3 Mat3::new_reflection(V3 axis) {  // mat3d.rs:66-80
+    axis = normalize(axis);
+    float a = axis[0], b = axis[1], c = axis[2];
+    Mat3 r;
+    r.m[0][0] = 1.0f - 2.0f * a * a;
+    r.m[0][1] = 0.0f - 2.0f * a * b;
+    r.m[0][2] = 0.0f - 2.0f * a * c;
+    r.m[1][0] = 0.0f - 2.0f * a * b;
+    r.m[1][1] = 1.0f - 2.0f * b * b;
+    r.m[1][2] = 0.0f - 2.0f * b * c;
+    r.m[2][0] = 0.0f - 2.0f * a * c;
+    r.m[2][1] = 0.0f * 2.0f * b * c;  // sic, mat3d.rs:78
+    r.m[2][2] = 1.0f - 2.0f * c * c;
+    return r;
+}
 Mat3 Mat3::multiply(const Mat3& a, const Mat3& b) {  // mat3d.rs:113-133
     Mat3 r;
     for (int i = 0; i < 3; i++)
@@ -792,6 +807,12 @@ bool Rotate::is_hit(const Ray& ray, float t_max) const {  // :192-198
 TransformBuilder& TransformBuilder::rotate(V3 axis, float angle) {  // transform.rs:255-260
     V3 off = mat.transpose_apply(offset);
     mat = Mat3::multiply(Mat3::new_rotation(axis, angle), mat);  // :138-142
+    offset = mat.apply(off);
+    return *this;
+}
+TransformBuilder& TransformBuilder::reflect(V3 axis) {  // transform.rs:274-279, Rotate::reflect :156-160
+    V3 off = mat.transpose_apply(offset);
+    mat = Mat3::multiply(Mat3::new_reflection(axis), mat);
     offset = mat.apply(off);
     return *this;
 }

@@ -113,6 +113,7 @@ struct Mat3 {
     float m[3][3];
     static Mat3 identity();
     static Mat3 new_rotation(V3 axis, float angle);      // mat3d.rs:47-64 (keeps the `1.0 * c` slip)
+    static Mat3 new_reflection(V3 axis);                 // mat3d.rs:66-80 (keeps the `0.0 * 2.0 * b * c` slip)
     static Mat3 multiply(const Mat3& a, const Mat3& b);  // mat3d.rs:113-133
     V3 apply(V3 a) const;                                 // mat3d.rs:139-153
     V3 transpose_apply(V3 a) const;                       // mat3d.rs:155-169
@@ -307,6 +308,7 @@ struct TransformBuilder {
     TransformBuilder& translate(V3 off) { offset = offset + off; return *this; }
     TransformBuilder& scale(float s) { scale_ = scale_ * s; offset = offset * s; return *this; }
     TransformBuilder& rotate(V3 axis, float angle);
+    TransformBuilder& reflect(V3 axis);                  // transform.rs:274-279
     GeomPtr build() const;
 };
 GeomPtr make_sphere(V3 center, float radius);  // sphere.rs:14-19

@@ -196,6 +196,10 @@ void* orc_scene_textured(const char* ply_path, const uint8_t* sky_rgb, int sky_w
         s->mesh2 = Mesh::from_triangles(tris);
         objs.push_back(std::make_shared<Object>(std::make_shared<Translate>(s->mesh2, V3(c[0] - 2.8f, c[1] + 1.6f, bb.min[2])), mat_lambert(tex_checkerboard(3))));
     }
+    // Transform::reflect + a rotation about a general axis (mat3d.rs:47-80 as written, slips included), then moved beside the floor's far corner
+    objs.push_back(std::make_shared<Object>(TransformBuilder(s->mesh).scale(9.0f).rotate(V3(1.f, 0.f, 0.f), 90.0f * (PI_F / 180.0f)).reflect(V3(0.f, 1.f, 0.f))
+                                                .rotate(V3(0.3f, 0.2f, 1.0f), 0.7f).translate(V3(c[0] + 2.6f, c[1] - 3.4f, bb.min[2] + 0.1f)).build(),
+                                            mat_lambert(tex_checkerboard(5))));
     auto list = std::make_shared<GeometryList>();
     for (auto& o : objs) list->items.push_back(o);
     finalize_object_ids(s, objs);
@@ -209,13 +213,17 @@ void* orc_scene_textured(const char* ply_path, const uint8_t* sky_rgb, int sky_w
 
 // Synthetic: nx*ny instances of the (scaled, rotated) mesh on a grid of pitch 4.0, materials cycling
 // Transparent / Metal / Lambertian by (ix+iy)%3, in one AABBTree<Object> (hit_cost 1.0) + floor.
-void* orc_scene_grid(const char* ply_path, int nx, int ny, const uint8_t* sky_rgb, int sky_w, int sky_h, int cam_w, int cam_h) {
+// flat != 0: every instance is a mesh of its own whose vertices are carried to world space in f32 the way a hit point
+// leaves the wrappers (rotate, scale, the Transform's own offset, the instance offset: transform.rs:183,108,61), with its
+// own normals and tree (Mesh::from_vertices) and no ray transform.
+void* orc_scene_grid2(const char* ply_path, int nx, int ny, int flat, const uint8_t* sky_rgb, int sky_w, int sky_h, int cam_w, int cam_h) {
     auto* s = new OrcScene();
     std::vector<V3> verts;
     std::vector<std::array<uint32_t, 3>> faces;
     if (!load_ply(ply_path, verts, faces, s->error)) { fprintf(stderr, "orc: %s\n", s->error.c_str()); delete s; return nullptr; }
     s->mesh = Mesh::from_vertices(verts, faces);
-    GeomPtr tmesh = TransformBuilder(s->mesh).scale(20.0f).rotate(V3(1.f, 0.f, 0.f), 90.0f * (PI_F / 180.0f)).build();
+    TransformBuilder tb = TransformBuilder(s->mesh).scale(20.0f).rotate(V3(1.f, 0.f, 0.f), 90.0f * (PI_F / 180.0f));
+    GeomPtr tmesh = tb.build();
     AABB bb = tmesh->bounding_box();
     const float pitch = 4.0f;
     float x0 = -0.5f * pitch * (float)(nx - 1), y0 = -0.5f * pitch * (float)(ny - 1);
@@ -230,8 +238,24 @@ void* orc_scene_grid(const char* ply_path, int nx, int ny, const uint8_t* sky_rg
                 case 1: m = mat_metal(); break;
                 default: m = mat_lambert(V3(1.f, 1.f, 1.f)); break;
             }
-            objs.emplace_back(std::make_shared<Translate>(tmesh, V3::fill(0.0f) + off), m);
+            objs.emplace_back(flat ? GeomPtr() : GeomPtr(std::make_shared<Translate>(tmesh, V3::fill(0.0f) + off)), m);
         }
+    if (flat) {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            std::vector<V3> wv(verts.size());
+            for (size_t k = next++; k < objs.size(); k = next++) {
+                const int ix = (int)(k % (size_t)nx), iy = (int)(k / (size_t)nx);
+                const V3 off = V3::fill(0.0f) + V3(x0 + pitch * (float)ix, y0 + pitch * (float)iy, 0.0f);
+                for (size_t v = 0; v < verts.size(); v++) wv[v] = ((tb.mat.apply(verts[v]) * tb.scale_) + tb.offset) + off;
+                objs[k].geometry = Mesh::from_vertices(wv, faces);
+            }
+        };
+        size_t nt = std::min<size_t>(16, std::max<size_t>(1, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++) th.emplace_back(work);
+        for (auto& t : th) t.join();
+    }
     s->object_tree = std::make_shared<AABBTree<Object>>(std::move(objs), 1.0f);
     float hx = 0.5f * pitch * (float)nx + 2.0f, hy = 0.5f * pitch * (float)ny + 2.0f;
     std::vector<std::shared_ptr<Object>> root_objs;
@@ -243,6 +267,46 @@ void* orc_scene_grid(const char* ply_path, int nx, int ny, const uint8_t* sky_rg
     finalize_object_ids(s, root_objs);
     float ext = hx > hy ? hx : hy;
     s->cam_pos = V3(-1.2f * ext, -1.2f * ext, 0.9f * ext); s->cam_focus = V3(0.0f, 0.0f, 0.0f); s->cam_up = -V3(0.f, 0.f, 1.f);
+    s->make_camera((size_t)cam_w, (size_t)cam_h);
+    s->scene.root = list;
+    s->scene.skybox = make_sky(sky_rgb, sky_w, sky_h);
+    s->scene.lights = main_lights();
+    return s;
+}
+
+void* orc_scene_grid(const char* ply_path, int nx, int ny, const uint8_t* sky_rgb, int sky_w, int sky_h, int cam_w, int cam_h) {
+    return orc_scene_grid2(ply_path, nx, ny, 0, sky_rgb, sky_w, sky_h, cam_w, cam_h);
+}
+
+// Synthetic: n small spheres and cuboids (alternating, splitmix64(seed): centre in [-6,6]^2 x [0.2,2.5], size in
+// [0.1,0.4], drawn cx, cy, cz, size) in a PLAIN GeometryList followed by a floor cuboid.  accelerate != 0 applies the
+// product's top-level extension: the run of plain objects becomes one AABBTree<Object> (hit_cost 1.0) in place.
+void* orc_scene_scatter(int n, uint64_t seed, int accelerate, const uint8_t* sky_rgb, int sky_w, int sky_h, int cam_w, int cam_h) {
+    auto* s = new OrcScene();
+    SplitMix64 g{seed};
+    std::vector<Object> run;
+    for (int i = 0; i < n; i++) {
+        float cx = -6.0f + 12.0f * g.uniform();
+        float cy = -6.0f + 12.0f * g.uniform();
+        float cz = 0.2f + 2.3f * g.uniform();
+        float r = 0.1f + 0.3f * g.uniform();
+        GeomPtr geom = (i % 2 == 0) ? make_sphere(V3(cx, cy, cz), r) : GeomPtr(std::make_shared<Cuboid>(V3(cx - r, cy - r, cz - r), V3(cx + r, cy + r, cz + r)));
+        Material m = (i % 3 == 0) ? mat_metal() : ((i % 3 == 1) ? mat_lambert(V3(1.f, 1.f, 1.f)) : mat_lambert(tex_checkerboard(4)));
+        run.emplace_back(geom, m);
+    }
+    auto floor = std::make_shared<Object>(std::make_shared<Cuboid>(V3(-8.0f, -8.0f, 0.0f), V3(8.0f, 8.0f, -1.0f)), mat_glossy(1e3f, 0.3f, V3(1.f, 1.f, 1.f)));
+    auto list = std::make_shared<GeometryList>();
+    std::vector<std::shared_ptr<Object>> root_objs;
+    if (accelerate && n >= 2) {
+        s->object_tree = std::make_shared<AABBTree<Object>>(std::move(run), 1.0f);
+        list->items.push_back(s->object_tree);
+    } else {
+        for (auto& o : run) root_objs.push_back(std::make_shared<Object>(o));
+    }
+    root_objs.push_back(floor);
+    for (auto& o : root_objs) list->items.push_back(o);
+    finalize_object_ids(s, root_objs);
+    s->cam_pos = V3(-9.0f, -9.0f, 6.0f); s->cam_focus = V3(0.0f, 0.0f, 0.8f); s->cam_up = -V3(0.f, 0.f, 1.f);
     s->make_camera((size_t)cam_w, (size_t)cam_h);
     s->scene.root = list;
     s->scene.skybox = make_sky(sky_rgb, sky_w, sky_h);

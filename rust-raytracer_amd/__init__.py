@@ -67,7 +67,7 @@ class Stats(C.Structure):  # rtamd_stats
 ABI_SYMBOLS = (
     "rtamd_create", "rtamd_destroy", "rtamd_last_error", "rtamd_upload_scene", "rtamd_trace_closest", "rtamd_trace_any",
     "rtamd_trace_closest_device", "rtamd_trace_any_device", "rtamd_region_pixels", "rtamd_render", "rtamd_render_device",
-    "rtamd_quantize_device", "rtamd_set_option", "rtamd_kernel_times", "rtamd_trace_closest_static",
+    "rtamd_quantize_device", "rtamd_set_option", "rtamd_kernel_times", "rtamd_trace_closest_static", "rtamd_render_multi",
 )
 
 
@@ -127,6 +127,14 @@ def host_lib():
         _host.rth_scene_textured.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_grid.restype = C.c_void_p
         _host.rth_scene_grid.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _host.rth_scene_grid2.restype = C.c_void_p
+        _host.rth_scene_grid2.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _host.rth_scene_scatter.restype = C.c_void_p
+        _host.rth_scene_scatter.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _host.rth_render_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.POINTER(Stats)]
+        _host.rth_ply_info.argtypes = [C.c_char_p, _u32p, _f32p, _u32p, C.c_int]
+        _host.rth_save_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        _host.rth_kat_reflection.argtypes = [_f32p, _f32p]
         _host.rth_scene_free.argtypes = [C.c_void_p]
         _host.rth_scene_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
         _host.rth_scene_upload.restype = C.c_void_p
@@ -184,9 +192,16 @@ class Scene:
         return cls(host_lib().rth_scene_spheres(n, seed, p, w, h, cam[0], cam[1]), sky)
 
     @classmethod
-    def grid(cls, nx, ny, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
+    def grid(cls, nx, ny, sky=None, cam=(1080, 960), ply=BUNNY_PLY, flat=False):
+        """nx x ny instanced bunnies in an object tree; flat: every instance a world-space mesh of its own."""
         sky, p, w, h = cls._sky_args(sky)
-        return cls(host_lib().rth_scene_grid(ply.encode(), nx, ny, p, w, h, cam[0], cam[1]), sky)
+        return cls(host_lib().rth_scene_grid2(ply.encode(), nx, ny, int(flat), p, w, h, cam[0], cam[1]), sky)
+
+    @classmethod
+    def scatter(cls, n, seed=1, accelerate=False, sky=None, cam=(1080, 960)):
+        """n spheres / cuboids in a plain GeometryList; accelerate: the list's top-level tree extension."""
+        sky, p, w, h = cls._sky_args(sky)
+        return cls(host_lib().rth_scene_scatter(n, seed, int(accelerate), p, w, h, cam[0], cam[1]), sky)
 
     @classmethod
     def terrain(cls, n, seed=1, with_bunny=True, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
@@ -324,6 +339,19 @@ class Scene:
         if n_tiles == 1:
             out = out[0]
         return out, st.as_dict()
+
+
+def render_multi(scene, device_ids, max_depth=5, shadow_rays=1, scatter_rays=1, antialiasing=1):
+    """render::parallel_render of the C++ host over several GPU contexts (rtamd_render_multi): one context per entry of
+    device_ids (ids may repeat), image tiles dealt round-robin, one host thread per context.  Returns (rgb[h, w, 3], stats)."""
+    cam = scene.camera()
+    out = np.zeros((cam.height, cam.width, 3), np.float32)
+    st = Stats()
+    ids = (C.c_int * len(device_ids))(*device_ids)
+    params = (C.c_int * 4)(max_depth, shadow_rays, scatter_rays, antialiasing)
+    if host_lib().rth_render_multi(scene.h, len(device_ids), ids, params, out.ctypes.data, C.byref(st)) != 0:
+        raise RtamdError("render_multi failed: " + host_lib().rth_last_error().decode())
+    return out, st.as_dict()
 
 
 def assemble_tiles(tiles, region_full, tile_first, tile_stride, image=None):

@@ -10,6 +10,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_kernels.h"
@@ -437,11 +438,26 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     if (sc->n_root == 0 || !sc->root) return fail(ctx, RTAMD_E_INVALID, "scene root is empty");
     if (sc->n_objects == 0 || !sc->objects) return fail(ctx, RTAMD_E_INVALID, "scene has no objects");
     if (sc->n_materials == 0 || !sc->materials) return fail(ctx, RTAMD_E_INVALID, "scene has no materials");
+    if ((sc->n_meshes && !sc->meshes) || (sc->n_cuboids && !sc->cuboids) || (sc->n_triangles && !sc->triangles) || (sc->n_ops && !sc->ops) ||
+        (sc->n_trees && !sc->trees) || (sc->n_lights && !sc->lights) || (sc->n_images && !sc->images))
+        return fail(ctx, RTAMD_E_INVALID, "a scene array is null although its count is not zero");
+    for (uint32_t k = 0; k < sc->n_ops; k++) {
+        const rtamd_xform_op& op = sc->ops[k];
+        // Scale::new asserts scale > 0 (transform.rs:87); the pair must be the reference's (s, 1.0 / s)
+        if (op.kind == RTAMD_OP_SCALE && !(op.v[0] > 0.0f && std::isfinite(op.v[0]) && op.v[1] == 1.0f / op.v[0]))
+            return fail(ctx, RTAMD_E_INVALID, "SCALE op: v[0] must be a positive finite scale and v[1] its reciprocal 1.0f / v[0]");
+    }
 
     std::vector<float4> nodes, tris, normals;
     std::vector<DevMesh> meshes;
     std::vector<DevTree> trees;
     int rc;
+    {
+        size_t nn = 0, nt = 0, nv = 0;
+        for (uint32_t m = 0; m < sc->n_meshes; m++) { nn += sc->meshes[m].n_nodes; nt += sc->meshes[m].n_tris; nv += sc->meshes[m].n_verts; }
+        for (uint32_t t = 0; t < sc->n_trees; t++) nn += sc->trees[t].n_nodes;
+        nodes.reserve(2 * nn); tris.reserve(3 * nt); normals.reserve(nv); meshes.reserve(sc->n_meshes);
+    }
     for (uint32_t m = 0; m < sc->n_meshes; m++) {
         const rtamd_mesh& me = sc->meshes[m];
         if (!me.tri_indices || !me.vertices || !me.normals) return fail(ctx, RTAMD_E_INVALID, "mesh with null arrays");
@@ -616,11 +632,20 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     if ((rc = upload_vec(ctx, images, &S.images))) return rc;
     S.n_root = sc->n_root; S.n_lights = sc->n_lights; S.sky_w = sw; S.sky_h = sh;
     S.n_objects = sc->n_objects; S.n_meshes = sc->n_meshes;
-    // LDS staging: the first mesh whose nodes + triangles fit in 52 KiB (three 512-thread blocks per CU)
+    // LDS staging: of the meshes whose nodes + triangles fit in 52 KiB (two 512-thread blocks per CU), the one that
+    // most objects instance, and only if at least a quarter of the mesh objects do (every block pays for the copy)
     S.lds_mesh = MISS; S.lds_bytes = 0;
-    for (uint32_t m = 0; m < sc->n_meshes; m++) {
-        size_t bytes = (size_t)meshes[m].n_nodes * 32 + (size_t)sc->meshes[m].n_tris * 48;
-        if (bytes > 0 && bytes <= 52 * 1024) { S.lds_mesh = m; S.lds_bytes = (uint32_t)bytes; break; }
+    {
+        std::vector<uint32_t> refs(sc->n_meshes, 0u);
+        uint32_t mesh_objects = 0;
+        for (const DevObject& o : objects)
+            if (o.geom_kind == GEOM_MESH) { refs[o.geom_index]++; mesh_objects++; }
+        uint32_t best_refs = 0;
+        for (uint32_t m = 0; m < sc->n_meshes; m++) {
+            const size_t bytes = (size_t)meshes[m].n_nodes * 32 + (size_t)sc->meshes[m].n_tris * 48;
+            if (bytes > 0 && bytes <= 52 * 1024 && refs[m] > best_refs) { S.lds_mesh = m; S.lds_bytes = (uint32_t)bytes; best_refs = refs[m]; }
+        }
+        if (S.lds_mesh != MISS && (uint64_t)best_refs * 4u < mesh_objects) { S.lds_mesh = MISS; S.lds_bytes = 0; }
     }
     // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
@@ -1002,6 +1027,62 @@ int rtamd_render(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integr
     }
     (void)hipFree(d);
     return rc;
+}
+
+int rtamd_render_multi(rtamd_context* const* ctxs, int n, const rtamd_camera* cam, const rtamd_integrator* integ, uint32_t x0, uint32_t y0,
+                       uint32_t w, uint32_t h, uint32_t tile_w, uint32_t tile_h, float* out, rtamd_stats* stats) {
+    if (!ctxs || n < 1 || !cam || !integ || !out) return RTAMD_E_INVALID;
+    for (int k = 0; k < n; k++)
+        if (!ctxs[k]) return RTAMD_E_INVALID;
+    if (w == 0 || h == 0 || tile_w == 0 || tile_h == 0) return fail(ctxs[0], RTAMD_E_INVALID, "bad region");
+    const uint32_t tiles_x = (w + tile_w - 1) / tile_w, tiles_y = (h + tile_h - 1) / tile_h;
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+    std::vector<int> rc((size_t)n, RTAMD_OK);
+    std::vector<rtamd_stats> st((size_t)n);
+    auto work = [&](int k) {
+        std::memset(&st[k], 0, sizeof(rtamd_stats));
+        if ((uint64_t)k >= n_tiles) return;   // more contexts than tiles
+        const rtamd_region reg{x0, y0, w, h, tile_w, tile_h, (uint32_t)k, (uint32_t)n};
+        const size_t px = rtamd_region_pixels(&reg);
+        std::vector<float> buf;
+        try { buf.resize(px * 3); } catch (...) { rc[k] = fail(ctxs[k], RTAMD_E_INVALID, "out of host memory for the tile buffer"); return; }
+        rc[k] = rtamd_render(ctxs[k], cam, integ, &reg, buf.data(), &st[k]);
+        if (rc[k] != RTAMD_OK) return;
+        // tile q of this context is tile k + q * n of the rectangle: copy its rows into the row-major frame
+        size_t q = 0;
+        for (uint64_t t = (uint64_t)k; t < n_tiles; t += (uint64_t)n, q++) {
+            const uint32_t ty = (uint32_t)(t / tiles_x), tx = (uint32_t)(t % tiles_x);
+            const uint32_t px0 = tx * tile_w, py0 = ty * tile_h;
+            const uint32_t cw = std::min(tile_w, w - px0), ch = std::min(tile_h, h - py0);
+            const float* src = buf.data() + q * (size_t)tile_w * tile_h * 3;
+            for (uint32_t r = 0; r < ch; r++)
+                std::memcpy(out + ((size_t)(py0 + r) * w + px0) * 3, src + (size_t)r * tile_w * 3, (size_t)cw * 12);
+        }
+    };
+    if (n == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve((size_t)n);
+        for (int k = 0; k < n; k++) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
+    }
+    for (int k = 0; k < n; k++)
+        if (rc[k] != RTAMD_OK) {
+            if (k != 0) ctxs[0]->error = "context " + std::to_string(k) + ": " + ctxs[k]->error;
+            return rc[k];
+        }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (int k = 0; k < n; k++) {
+            stats->closest_rays += st[k].closest_rays; stats->any_rays += st[k].any_rays; stats->paths += st[k].paths; stats->launches += st[k].launches;
+            stats->device_ms = std::max(stats->device_ms, st[k].device_ms);
+            stats->trace_closest_ms = std::max(stats->trace_closest_ms, st[k].trace_closest_ms);
+            stats->trace_any_ms = std::max(stats->trace_any_ms, st[k].trace_any_ms);
+            stats->shade_ms = std::max(stats->shade_ms, st[k].shade_ms);
+        }
+    }
+    return RTAMD_OK;
 }
 
 int rtamd_quantize_device(rtamd_context* ctx, const float* rgb, size_t n, uint8_t* out) {

@@ -428,9 +428,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     bool skip = false;
                     if (ob.xf_kind & XF_BOX) {
                         const ObjBox ox = tab.object_box(oi);
-                        float bt0, bt1;
-                        box_roots(wpos, winv, ox.mn, ox.mx, bt0, bt1);
-                        skip = (bt0 > bt1) || (bt0 > wtmax * 1.00001f + ox.slack) || (bt1 < -ox.slack);
+                        // The slab roots carry a rounding error of a few ulps of the largest plane distance, which for a far
+                        // origin exceeds the fixed pad of the box: the interval is widened by that much before it is judged.
+                        const f3 pa = (ox.mn - wpos) * winv, pb = (ox.mx - wpos) * winv;
+                        const float bt0 = max2(min2(pa.x, pb.x), max2(min2(pa.y, pb.y), min2(pa.z, pb.z)));
+                        const float bt1 = min2(max2(pa.x, pb.x), min2(max2(pa.y, pb.y), max2(pa.z, pb.z)));
+                        const float err = 1e-6f * fmaxf(fabsf(bt0), fabsf(bt1)) + ox.slack;   // NaN or inf roots: nothing is skipped
+                        skip = (bt0 > bt1 + err) || (bt0 > wtmax * 1.00001f + err) || (bt1 < -err);
                     }
                     if (!skip) {
                     const ObjXf xf = tab.object_xf(oi);   // read with the head: one LDS round trip instead of two

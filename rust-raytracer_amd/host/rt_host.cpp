@@ -56,6 +56,21 @@ Mat3D Mat3D::new_rotation(Vec3D axis, float angle) {
     r.m[8] = c + z * z * (1.0f - c);
     return r;
 }
+Mat3D Mat3D::new_reflection(Vec3D axis) {  // mat3d.rs:66-80
+    axis = axis.normalize();
+    float a = axis.x, b = axis.y, c = axis.z;
+    Mat3D r;
+    r.m[0] = 1.0f - 2.0f * a * a;
+    r.m[1] = 0.0f - 2.0f * a * b;
+    r.m[2] = 0.0f - 2.0f * a * c;
+    r.m[3] = 0.0f - 2.0f * a * b;
+    r.m[4] = 1.0f - 2.0f * b * b;
+    r.m[5] = 0.0f - 2.0f * b * c;
+    r.m[6] = 0.0f - 2.0f * a * c;
+    r.m[7] = 0.0f * 2.0f * b * c;  // as the reference writes it (mat3d.rs:78)
+    r.m[8] = 1.0f - 2.0f * c * c;
+    return r;
+}
 Mat3D Mat3D::multiply(const Mat3D& a, const Mat3D& b) {
     Mat3D r;
     for (int i = 0; i < 3; i++)
@@ -281,8 +296,9 @@ uint32_t FlatScene::image_index(const std::shared_ptr<const Image>& img) {
     return (uint32_t)(images.size() - 1);
 }
 uint32_t FlatScene::mesh_index(const std::shared_ptr<const Mesh>& m) {
-    for (size_t k = 0; k < mesh_refs.size(); k++)
-        if (mesh_refs[k].get() == m.get()) return (uint32_t)k;
+    auto it = mesh_lookup.find(m.get());
+    if (it != mesh_lookup.end()) return it->second;
+    mesh_lookup.emplace(m.get(), (uint32_t)mesh_refs.size());
     mesh_refs.push_back(m);
     rtamd_mesh d;
     d.nodes = m->tree.nodes.data(); d.n_nodes = (uint32_t)m->tree.nodes.size();
@@ -456,6 +472,13 @@ std::shared_ptr<Transform> Transform::rotate(Vec3D axis, float angle) const {  /
     t->offset = t->mat.apply(off);
     return t;
 }
+std::shared_ptr<Transform> Transform::reflect(Vec3D axis) const {  // transform.rs:274-279, Rotate::reflect :156-160
+    auto t = std::make_shared<Transform>(*this);
+    Vec3D off = mat.transpose_apply(offset);
+    t->mat = Mat3D::multiply(Mat3D::new_reflection(axis), mat);
+    t->offset = t->mat.apply(off);
+    return t;
+}
 GeomPtr Transform::chain() const {
     GeomPtr r = std::make_shared<Rotate>(obj, mat);
     GeomPtr s = std::make_shared<Scale>(r, scale_);
@@ -484,6 +507,26 @@ GeometryList GeometryList::from_vec(std::vector<Object> v) {
     GeometryList l;
     for (auto& o : v) l.push(o);
     return l;
+}
+size_t GeometryList::accelerate(size_t min_run) {
+    std::vector<Item> out;
+    size_t built = 0;
+    for (size_t k = 0; k < items.size();) {
+        size_t e = k;
+        while (e < items.size() && !items[e].is_tree) e++;
+        if (e - k >= min_run && e - k >= 2) {
+            std::vector<Object> run;
+            for (size_t q = k; q < e; q++) run.push_back(items[q].object);
+            out.push_back(Item{true, Object(), ObjectTree::make(std::move(run), 1.0f)});
+            built++;
+        } else {
+            for (size_t q = k; q < e; q++) out.push_back(items[q]);
+        }
+        if (e < items.size()) out.push_back(items[e++]);
+        k = e;
+    }
+    items = std::move(out);
+    return built;
 }
 AABB GeometryList::bounding_box() const {
     AABB b;
@@ -532,7 +575,7 @@ void Device::check(int rc, const char* what) const {
     if (rc != RTAMD_OK) throw GpuError(std::string(what) + ": " + rtamd_last_error(ctx));
 }
 
-void Scene::upload(Device& dev) {
+void Scene::flatten() {
     auto fs = std::make_shared<FlatScene>();
     auto add_material = [&](const Material& m) {
         rtamd_material flat = m.m;
@@ -563,6 +606,15 @@ void Scene::upload(Device& dev) {
         }
     }
     for (const Light& l : lights) fs->lights.push_back(l.l);
+    flat_ = fs;
+}
+void Scene::upload(Device& dev) {
+    flatten();
+    upload_flat(dev);
+}
+void Scene::upload_flat(Device& dev) {
+    if (!flat_) flatten();
+    const FlatScene* fs = flat_.get();
     rtamd_scene_desc d{};
     d.meshes = fs->meshes.data(); d.n_meshes = (uint32_t)fs->meshes.size();
     d.cuboids = fs->cuboids.data(); d.n_cuboids = (uint32_t)fs->cuboids.size();
@@ -576,7 +628,6 @@ void Scene::upload(Device& dev) {
     if (skybox) { d.skybox_rgb = skybox->rgb.data(); d.sky_w = skybox->width; d.sky_h = skybox->height; }
     d.images = fs->images.data(); d.n_images = (uint32_t)fs->images.size();
     dev.check(rtamd_upload_scene(dev.ctx, &d), "rtamd_upload_scene");
-    flat_ = fs;
 }
 void Scene::hit(Device& dev, const rtamd_rays& rays, size_t n, const rtamd_hits& out) const {
     dev.check(rtamd_trace_closest(dev.ctx, &rays, n, &out), "rtamd_trace_closest");
@@ -605,6 +656,26 @@ std::vector<float> parallel_render(Device& dev, const Scene& scene, const Whitte
     }
     return buffer;
 }
+std::vector<float> parallel_render(const std::vector<Device*>& devs, const Scene& scene, const WhittedIntegrator& integ, rtamd_stats* stats, bool quiet) {
+    if (devs.empty()) throw GpuError("parallel_render: no device");
+    const size_t width = scene.camera.width, height = scene.camera.height;
+    std::vector<float> buffer(width * height * 3);
+    rtamd_camera cam = scene.camera.flat();
+    rtamd_integrator ig = integ.flat();
+    std::vector<rtamd_context*> ctxs;
+    for (Device* d : devs) ctxs.push_back(d->ctx);
+    auto before = std::chrono::steady_clock::now();
+    devs[0]->check(rtamd_render_multi(ctxs.data(), (int)ctxs.size(), &cam, &ig, 0, 0, (uint32_t)width, (uint32_t)height, 64, 64, buffer.data(), stats),
+                   "rtamd_render_multi");
+    double time = std::chrono::duration<double>(std::chrono::steady_clock::now() - before).count();
+    if (!quiet) {
+        int minutes = (int)std::floor(time / 60.0);
+        int seconds = (int)std::ceil(std::fmod(time, 60.0));
+        std::printf("Rendered %zux%zu=%zu pixels in %02d:%02d (%.3f sec/pixel)\n", width, height, width * height, minutes, seconds,
+                    time / ((double)width * (double)height));  // render.rs:45-53
+    }
+    return buffer;
+}
 std::vector<uint8_t> parallel_render_image(Device& dev, const Scene& scene, const WhittedIntegrator& integ) {
     std::vector<float> buffer = parallel_render(dev, scene, integ);
     std::vector<uint8_t> px(buffer.size());
@@ -622,6 +693,59 @@ void save_ppm(const std::string& path, const std::vector<uint8_t>& rgb, size_t w
     if (!f) throw std::runtime_error("cannot write " + path);
     f << "P6\n" << w << " " << h << "\n255\n";
     f.write((const char*)rgb.data(), (std::streamsize)rgb.size());
+}
+void save_png(const std::string& path, const std::vector<uint8_t>& rgb, size_t w, size_t h) {
+    if (rgb.size() != w * h * 3 || w == 0 || h == 0 || w > 0x7FFFFFFFu || h > 0x7FFFFFFFu) throw std::runtime_error("save_png: bad image size");
+    static uint32_t table[256];
+    static bool have = false;
+    if (!have) {
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+        have = true;
+    }
+    auto be32 = [](std::string& o, uint32_t v) { o.push_back((char)(v >> 24)); o.push_back((char)(v >> 16)); o.push_back((char)(v >> 8)); o.push_back((char)v); };
+    auto chunk = [&](std::string& file, const char type[4], const std::string& data) {
+        be32(file, (uint32_t)data.size());
+        std::string body(type, 4);
+        body += data;
+        uint32_t c = 0xFFFFFFFFu;
+        for (unsigned char ch : body) c = table[(c ^ ch) & 0xFFu] ^ (c >> 8);
+        file += body;
+        be32(file, c ^ 0xFFFFFFFFu);
+    };
+    // scanlines with filter type 0, wrapped in a zlib stream of stored (uncompressed) deflate blocks
+    std::string raw;
+    raw.reserve((w * 3 + 1) * h);
+    for (size_t y = 0; y < h; y++) {
+        raw.push_back('\0');
+        raw.append((const char*)rgb.data() + y * w * 3, w * 3);
+    }
+    std::string z;
+    z.push_back((char)0x78); z.push_back((char)0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back((char)(pos + n == raw.size() ? 1 : 0));
+        z.push_back((char)(n & 0xFF)); z.push_back((char)(n >> 8));
+        z.push_back((char)(~n & 0xFF)); z.push_back((char)((~n >> 8) & 0xFF));
+        z.append(raw, pos, n);
+        for (size_t k = 0; k < n; k++) { a = (a + (unsigned char)raw[pos + k]) % 65521u; b = (b + a) % 65521u; }
+        pos += n;
+    }
+    be32(z, (b << 16) | a);
+    std::string file("\x89PNG\r\n\x1a\n", 8);
+    std::string ihdr;
+    be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h);
+    ihdr.push_back((char)8); ihdr.push_back((char)2); ihdr.push_back('\0'); ihdr.push_back('\0'); ihdr.push_back('\0');
+    chunk(file, "IHDR", ihdr);
+    chunk(file, "IDAT", z);
+    chunk(file, "IEND", std::string());
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write " + path);
+    f.write(file.data(), (std::streamsize)file.size());
 }
 }  // namespace render
 
@@ -648,8 +772,35 @@ std::string scalar_type(const std::string& t) {
 }
 }  // namespace
 
+namespace {
+size_t scalar_size(const std::string& t) {
+    if (t == "int8" || t == "uint8") return 1;
+    if (t == "int16" || t == "uint16") return 2;
+    if (t == "int32" || t == "uint32" || t == "float32") return 4;
+    return 8;  // float64
+}
+// One scalar of a binary PLY body as a double (every PLY scalar type is exactly representable) and, for float32, its bits.
+bool read_scalar(std::istream& f, const std::string& type, bool big_endian, double& value, float& as_f32) {
+    unsigned char b[8];
+    const size_t n = scalar_size(type);
+    f.read((char*)b, (std::streamsize)n);
+    if (!f) return false;
+    if (big_endian) std::reverse(b, b + n);
+    as_f32 = 0.0f;
+    if (type == "int8") { int8_t v; std::memcpy(&v, b, 1); value = v; }
+    else if (type == "uint8") { value = b[0]; }
+    else if (type == "int16") { int16_t v; std::memcpy(&v, b, 2); value = v; }
+    else if (type == "uint16") { uint16_t v; std::memcpy(&v, b, 2); value = v; }
+    else if (type == "int32") { int32_t v; std::memcpy(&v, b, 4); value = v; }
+    else if (type == "uint32") { uint32_t v; std::memcpy(&v, b, 4); value = v; }
+    else if (type == "float32") { std::memcpy(&as_f32, b, 4); value = as_f32; }
+    else { std::memcpy(&value, b, 8); }
+    return true;
+}
+}  // namespace
+
 void load_ply(const std::string& path, std::vector<Vec3D>& vertices, std::vector<std::array<uint32_t, 3>>& faces) {
-    std::ifstream f(path);
+    std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("Error while reading file: " + path);
     size_t lineno = 0;
     std::vector<std::string> cur;
@@ -662,7 +813,11 @@ void load_ply(const std::string& path, std::vector<Vec3D>& vertices, std::vector
     next();
     if (cur != std::vector<std::string>{"ply"}) throw err("expecting 'ply'");
     next();
-    if (cur != std::vector<std::string>{"format", "ascii", "1.0"}) throw err("expected 'format ascii 1.0'");
+    // ply.rs:89-91 accepts `format ascii 1.0` only; the two binary forms are this loader's extension
+    enum { ASCII, BINARY_LE, BINARY_BE } format = ASCII;
+    if (cur == std::vector<std::string>{"format", "binary_little_endian", "1.0"}) format = BINARY_LE;
+    else if (cur == std::vector<std::string>{"format", "binary_big_endian", "1.0"}) format = BINARY_BE;
+    else if (cur != std::vector<std::string>{"format", "ascii", "1.0"}) throw err("expected 'format ascii 1.0'");
     struct Element { std::string name; size_t count; std::vector<std::pair<std::string, std::string>> props; };
     std::vector<Element> elements;
     next();
@@ -690,6 +845,64 @@ void load_ply(const std::string& path, std::vector<Vec3D>& vertices, std::vector
         elements.push_back(e);
     }
     if (cur != std::vector<std::string>{"end_header"}) throw err("expected 'end_header'");
+    if (format != ASCII) {
+        // The body follows the header byte for byte: elements in header order, properties in declaration order.
+        const bool be = format == BINARY_BE;
+        for (const Element& e : elements) {
+            const bool is_vertex = e.name == "vertex", is_face = e.name == "face";
+            int xi = -1, yi = -1, zi = -1, index = -1;
+            for (size_t k = 0; k < e.props.size(); k++) {
+                const auto& pr = e.props[k];
+                if (is_vertex && pr.second == "float32") {
+                    if (pr.first == "x") xi = (int)k;
+                    if (pr.first == "y") yi = (int)k;
+                    if (pr.first == "z") zi = (int)k;
+                }
+                if (is_face && index < 0 && (pr.first == "vertex_indices" || pr.first == "vertex_index") && pr.second.rfind("list ", 0) == 0 &&
+                    pr.second.find("float") == std::string::npos)
+                    index = (int)k;
+            }
+            if (is_vertex && xi < 0) throw err("vertex has no x property");
+            if (is_vertex && yi < 0) throw err("vertex has no y property");
+            if (is_vertex && zi < 0) throw err("vertex has no z property");
+            if (is_face && index < 0) throw err("face has not vertex_indices property");
+            if (!is_vertex && !is_face) std::fprintf(stderr, "WARN: ignoring element \"%s\"\n", e.name.c_str());
+            std::vector<uint32_t> idx;
+            for (size_t k = 0; k < e.count; k++) {
+                float xyz[3] = {0.f, 0.f, 0.f};
+                for (size_t q = 0; q < e.props.size(); q++) {
+                    const std::string& type = e.props[q].second;
+                    double v;
+                    float fv;
+                    if (type.rfind("list ", 0) != 0) {
+                        if (!read_scalar(f, type, be, v, fv)) throw err("unexpected end of the binary body");
+                        if ((int)q == xi) xyz[0] = fv;
+                        if ((int)q == yi) xyz[1] = fv;
+                        if ((int)q == zi) xyz[2] = fv;
+                        continue;
+                    }
+                    const size_t sp = type.find(' ', 5);
+                    const std::string count_type = type.substr(5, sp - 5), item_type = type.substr(sp + 1);
+                    if (!read_scalar(f, count_type, be, v, fv) || v < 0) throw err("unexpected end of the binary body");
+                    const size_t n = (size_t)v;
+                    const bool take = is_face && (int)q == index;
+                    if (take && n < 3) throw err("invalid number of vertices");
+                    idx.clear();
+                    for (size_t w = 0; w < n; w++) {
+                        if (!read_scalar(f, item_type, be, v, fv)) throw err("unexpected end of the binary body");
+                        if (!take) continue;
+                        if (v < 0 || v >= (double)vertices.size())
+                            throw err("invalid vertex identifier " + std::to_string((long long)v) + ", only " + std::to_string(vertices.size()) + " vertices");
+                        idx.push_back((uint32_t)v);
+                    }
+                    if (take)
+                        for (size_t w = 2; w < idx.size(); w++) faces.push_back({idx[0], idx[w - 1], idx[w]});  // fan, ply.rs:246-248
+                }
+                if (is_vertex) vertices.push_back(Vec3D(xyz[0], xyz[1], xyz[2]));
+            }
+        }
+        return;
+    }
     for (const Element& e : elements) {
         if (e.name == "vertex") {
             int xi = -1, yi = -1, zi = -1;

@@ -12,6 +12,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "rtamd.h"
@@ -62,6 +63,7 @@ struct Mat3D {
     float m[9];  // row-major
     static Mat3D identity();
     static Mat3D new_rotation(Vec3D axis, float angle);   // mat3d.rs:47-64, including its `1.0 * c` term
+    static Mat3D new_reflection(Vec3D axis);              // mat3d.rs:66-80, including its `0.0 * 2.0 * b * c` term
     static Mat3D multiply(const Mat3D& a, const Mat3D& b);
     Vec3D apply(Vec3D a) const;
     Vec3D transpose_apply(Vec3D a) const;
@@ -112,6 +114,7 @@ struct Image {  // texture::Image, texture.rs:49-68 (decoded RGB8; PPM P6 reader
 struct Mesh;
 struct FlatScene {  // owns every array rtamd_scene_desc points to
     std::vector<std::shared_ptr<const Mesh>> mesh_refs;
+    std::unordered_map<const Mesh*, uint32_t> mesh_lookup;
     std::vector<rtamd_mesh> meshes;
     std::vector<rtamd_cuboid> cuboids;
     std::vector<rtamd_triangle> triangles;
@@ -218,6 +221,10 @@ struct Transform : Geometry {  // Translate<Scale<Rotate<T>>>, transform.rs:223-
     std::shared_ptr<Transform> rotate_x(float a) const { return rotate(Vec3D::x_axis(), a); }
     std::shared_ptr<Transform> rotate_y(float a) const { return rotate(Vec3D::y_axis(), a); }
     std::shared_ptr<Transform> rotate_z(float a) const { return rotate(Vec3D::z_axis(), a); }
+    std::shared_ptr<Transform> reflect(Vec3D axis) const;   // transform.rs:274-279
+    std::shared_ptr<Transform> reflect_x() const { return reflect(Vec3D::x_axis()); }
+    std::shared_ptr<Transform> reflect_y() const { return reflect(Vec3D::y_axis()); }
+    std::shared_ptr<Transform> reflect_z() const { return reflect(Vec3D::z_axis()); }
     GeomPtr chain() const;  // the explicit Translate(Scale(Rotate(obj)))
     AABB bounding_box() const override { return chain()->bounding_box(); }
     void flatten(FlatScene& fs, std::vector<rtamd_xform_op>& ops, uint32_t material) const override { chain()->flatten(fs, ops, material); }
@@ -241,6 +248,11 @@ struct GeometryList {  // aggregate.rs:7-56
     struct Item { bool is_tree; Object object; std::shared_ptr<const ObjectTree> tree; };
     std::vector<Item> items;
     static GeometryList from_vec(std::vector<Object> v);
+    // Extension (the reference walks a GeometryList linearly, aggregate.rs:24-45): every run of at least `min_run` plain
+    // objects of the list is replaced by one AABBTree<Object> (bvh.rs:173, hit_cost 1.0) over the run, in place.  The hits
+    // are those of the list except where two objects of a run are hit at exactly the same t (the list reports the later
+    // object, the tree the later one in tree order).  Returns the number of trees built.
+    size_t accelerate(size_t min_run = 16);
     void push(Object o) { items.push_back(Item{false, o, nullptr}); }
     void push(std::shared_ptr<const ObjectTree> t) { items.push_back(Item{true, Object(), t}); }
     AABB bounding_box() const;
@@ -281,8 +293,11 @@ struct Scene {  // scene.rs:8-13
     std::vector<Light> lights;
     Camera camera = Camera(1, 1);
 
-    // Flatten + copy to the GPU (must be called again after the scene changes).
+    // Flatten + copy to a GPU (must be called again after the scene changes).  For several GPUs: upload() to the first,
+    // upload_flat() (the arrays of the last flatten()) to the others.
+    void flatten();
     void upload(Device& dev);
+    void upload_flat(Device& dev);
     const FlatScene& flat() const { return *flat_; }
 
     // Batched Geometry::hit / is_hit on the root (geom/mod.rs:30-33).
@@ -296,13 +311,21 @@ private:
 namespace render {
 // render.rs:10-56: linear RGB, row-major width*height*3; prints the reference's timing line.
 std::vector<float> parallel_render(Device& dev, const Scene& scene, const WhittedIntegrator& integ, rtamd_stats* stats = nullptr, bool quiet = false);
+// The same frame over several GPU contexts (the scene uploaded to each): 64x64 image tiles dealt round-robin, one host
+// thread per context, tiles written straight into the row-major frame (rtamd_render_multi).  Pixels are identical to the
+// single-context frame: a pixel's random stream depends on its coordinates only (integrator.rs:36).
+std::vector<float> parallel_render(const std::vector<Device*>& devs, const Scene& scene, const WhittedIntegrator& integ, rtamd_stats* stats = nullptr, bool quiet = false);
 // render.rs:58-75: quantised RGB8 image.
 std::vector<uint8_t> parallel_render_image(Device& dev, const Scene& scene, const WhittedIntegrator& integ);
 void save_ppm(const std::string& path, const std::vector<uint8_t>& rgb, size_t w, size_t h);
+// RGB8 PNG (main.rs:100 saves test_{i}.png through the image crate): stored deflate blocks, no compression.
+void save_png(const std::string& path, const std::vector<uint8_t>& rgb, size_t w, size_t h);
 }  // namespace render
 
 namespace loader {
-// loader/ply.rs:254-282 (ASCII PLY; the element name is token 1 of the `element` line).
+// loader/ply.rs:254-282 (ASCII PLY; the element name is token 1 of the `element` line).  Extension: `format
+// binary_little_endian 1.0` / `binary_big_endian 1.0` files (which ply.rs:89-91 rejects) are read too, so that the
+// 69 451-face bunny main.rs:24 names can be loaded in the form it is usually distributed in.
 void load_ply(const std::string& path, std::vector<Vec3D>& vertices, std::vector<std::array<uint32_t, 3>>& faces);
 std::shared_ptr<Mesh> load_ply_as_mesh(const std::string& path);
 }  // namespace loader
@@ -312,7 +335,10 @@ std::shared_ptr<Mesh> load_ply_as_mesh(const std::string& path);
 Scene scene_main(const std::string& ply_path, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 // Synthetic scenes of the larger benchmark configurations (generator: splitmix64, see rt_scenes.cpp).
 Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
-Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
+// flat: every instance is a mesh of its own with world-space vertices (no ray transform), see rt_scenes.cpp
+Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, bool flat = false);
+// n spheres and cuboids in a plain GeometryList (the top-level extension's test scene)
+Scene scene_scatter(int n, uint64_t seed, bool accelerate, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 Scene scene_terrain(const std::string& ply_path, int n, uint64_t seed, bool with_bunny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 Scene scene_textured(const std::string& ply_path, std::shared_ptr<const Image> skybox, std::shared_ptr<const Image> tex, size_t cam_w, size_t cam_h);
 

@@ -11,6 +11,7 @@ namespace {
 struct Handle {
     Scene scene;
     std::unique_ptr<Device> dev;
+    std::vector<std::unique_ptr<Device>> more;   // further contexts of rth_render_multi
     std::string error;
 };
 thread_local std::string g_error;
@@ -42,6 +43,12 @@ void* rth_scene_spheres(int n, uint64_t seed, const uint8_t* sky, int sw, int sh
 }
 void* rth_scene_grid(const char* ply, int nx, int ny, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
+}
+void* rth_scene_grid2(const char* ply, int nx, int ny, int flat, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
+    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h, flat != 0); return h; });
+}
+void* rth_scene_scatter(int n, uint64_t seed, int accelerate, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
+    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_scatter(n, seed, accelerate != 0, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
 }
 void* rth_scene_terrain(const char* ply, int n, uint64_t seed, int with_bunny, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_terrain(ply, n, seed, with_bunny != 0, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
@@ -142,6 +149,59 @@ int rth_render(void* p, const int params[4], float* out, rtamd_stats* stats) {
         g_error = e.what();
         return -1;
     }
+}
+
+// render::parallel_render over n_ctx contexts: context k lives on GPU device_ids[k] (the same id may repeat: several
+// contexts on one GPU).  The scene is uploaded to every context on first use.  out = width*height*3 floats.
+int rth_render_multi(void* p, int n_ctx, const int* device_ids, const int params[4], float* out, rtamd_stats* stats) {
+    Handle* h = (Handle*)p;
+    try {
+        if (n_ctx < 1) throw std::runtime_error("no context");
+        if (!h->dev) { h->dev.reset(new Device(device_ids[0])); h->scene.upload(*h->dev); }
+        while ((int)h->more.size() < n_ctx - 1) {
+            h->more.emplace_back(new Device(device_ids[h->more.size() + 1]));
+            h->scene.upload_flat(*h->more.back());
+        }
+        std::vector<Device*> devs{h->dev.get()};
+        for (int k = 0; k < n_ctx - 1; k++) devs.push_back(h->more[k].get());
+        WhittedIntegrator ig;
+        ig.max_depth = params[0]; ig.shadow_rays = params[1]; ig.scatter_rays = params[2]; ig.antialiasing = params[3];
+        std::vector<float> buf = render::parallel_render(devs, h->scene, ig, stats, true);
+        std::memcpy(out, buf.data(), buf.size() * 4);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+// Loader and image-writer probes for the tests.
+int rth_ply_info(const char* path, uint32_t counts[2], float* first_vertices, uint32_t* first_faces, int n_first) {
+    try {
+        std::vector<Vec3D> v;
+        std::vector<std::array<uint32_t, 3>> f;
+        loader::load_ply(path, v, f);
+        counts[0] = (uint32_t)v.size(); counts[1] = (uint32_t)f.size();
+        for (int k = 0; k < n_first && k < (int)v.size(); k++) { first_vertices[3 * k] = v[k].x; first_vertices[3 * k + 1] = v[k].y; first_vertices[3 * k + 2] = v[k].z; }
+        for (int k = 0; k < n_first && k < (int)f.size(); k++) { first_faces[3 * k] = f[k][0]; first_faces[3 * k + 1] = f[k][1]; first_faces[3 * k + 2] = f[k][2]; }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+int rth_save_png(const char* path, const uint8_t* rgb, int w, int h) {
+    try {
+        render::save_png(path, std::vector<uint8_t>(rgb, rgb + (size_t)w * h * 3), (size_t)w, (size_t)h);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+void rth_kat_reflection(const float axis[3], float out[9]) {
+    Mat3D m = Mat3D::new_reflection(Vec3D(axis[0], axis[1], axis[2]));
+    std::memcpy(out, m.m, 36);
 }
 
 }  // extern "C"

@@ -2,6 +2,10 @@
 // used for the larger benchmark configurations.
 #include "rt_host.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 namespace rth {
 
 static std::vector<Light> main_lights() {  // main.rs:67-76
@@ -81,9 +85,17 @@ Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, s
 // nx * ny instances of the scaled + rotated mesh on a grid of pitch 4.0 (row-major, x fastest),
 // materials cycling Transparent / Metal / Lambertian by (ix + iy) % 3, in one AABBTree<Object> with
 // hit_cost 1.0, above a glossy floor cuboid.
-Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h) {
-    auto mesh = loader::load_ply_as_mesh(ply_path);
-    GeomPtr tmesh = Transform::make(mesh)->scale(20.0f)->rotate_x(to_radians(90.0f));
+// flat: the world-space form of the same scene.  Every instance is a mesh of its own whose vertices are carried to world
+// space in f32 the way a hit point leaves the wrappers (rotate, scale, the Transform's own offset, the instance offset:
+// transform.rs:183,108,61), with its own normals and tree (Mesh::from_vertices) and no ray transform: nx * ny * 948
+// world-space triangles in nx * ny trees (230 x 230: 50.1 M triangles, 2.4 GB of triangle records).
+Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, bool flat) {
+    std::vector<Vec3D> verts;
+    std::vector<std::array<uint32_t, 3>> faces;
+    loader::load_ply(ply_path, verts, faces);
+    auto mesh = Mesh::from_vertices(verts, faces);
+    auto tform = Transform::make(mesh)->scale(20.0f)->rotate_x(to_radians(90.0f));
+    GeomPtr tmesh = tform;
     AABB bb = tmesh->bounding_box();
     const float pitch = 4.0f;
     float x0 = -0.5f * pitch * (float)(nx - 1), y0 = -0.5f * pitch * (float)(ny - 1);
@@ -93,8 +105,24 @@ Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<co
         for (int ix = 0; ix < nx; ix++) {
             Vec3D off(x0 + pitch * (float)ix, y0 + pitch * (float)iy, 0.0f);
             Material m = ((ix + iy) % 3 == 0) ? Transparent(1.0f / 0.6f) : (((ix + iy) % 3 == 1) ? Metal() : Lambartian(COLOR_WHITE));
-            objs.push_back(Object::with_material(Translate::make(tmesh)->translate(off), m));
+            objs.push_back(Object::with_material(flat ? GeomPtr() : GeomPtr(Translate::make(tmesh)->translate(off)), m));
         }
+    if (flat) {   // the instances' meshes, built on up to 16 host threads
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            std::vector<Vec3D> wv(verts.size());
+            for (size_t k = next++; k < objs.size(); k = next++) {
+                const int ix = (int)(k % (size_t)nx), iy = (int)(k / (size_t)nx);
+                const Vec3D off = Vec3D::zero() + Vec3D(x0 + pitch * (float)ix, y0 + pitch * (float)iy, 0.0f);
+                for (size_t v = 0; v < verts.size(); v++) wv[v] = ((tform->mat.apply(verts[v]) * tform->scale_) + tform->offset) + off;
+                objs[k].geometry = Mesh::from_vertices(wv, faces);
+            }
+        };
+        const size_t nt = std::min<size_t>(16, std::max<size_t>(1, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++) th.emplace_back(work);
+        for (auto& t : th) t.join();
+    }
     float hx = 0.5f * pitch * (float)nx + 2.0f, hy = 0.5f * pitch * (float)ny + 2.0f;
     Scene scene;
     scene.root.push(ObjectTree::make(std::move(objs), 1.0f));
@@ -178,10 +206,38 @@ Scene scene_textured(const std::string& ply_path, std::shared_ptr<const Image> s
         auto tetra = Mesh::from_triangles({{p0, p2, p1}, {p0, p1, p3}, {p1, p2, p3}, {p2, p0, p3}});
         list.push_back(Object::with_material(std::make_shared<Translate>(tetra, Vec3D(c.x - 2.8f, c.y + 1.6f, bb.min.z)), Lambartian(Checkerboard(3))));
     }
+    // Transform::reflect + a rotation about a general axis (mat3d.rs:47-80 as written, slips included), beside the floor's far corner
+    list.push_back(Object::with_material(Transform::make(mesh)->scale(9.0f)->rotate_x(to_radians(90.0f))->reflect_y()->rotate(Vec3D(0.3f, 0.2f, 1.0f), 0.7f)
+                                             ->translate(Vec3D(c.x + 2.6f, c.y - 3.4f, bb.min.z + 0.1f)),
+                                         Lambartian(Checkerboard(5))));
     Scene scene;
     for (auto& o : list) scene.root.push(o);
     Camera cam(cam_w, cam_h);
     cam.position(Vec3D(-6.0f, -6.0f, 3.0f)).look_at(c + Vec3D(0.0f, 0.0f, 0.1f), -Vec3D::z_axis());
+    scene.camera = cam;
+    scene.skybox = skybox;
+    scene.lights = main_lights();
+    return scene;
+}
+
+// n small spheres and cuboids (alternating, splitmix64(seed): centre in [-6,6]^2 x [0.2,2.5], size in [0.1,0.4], drawn
+// cx, cy, cz, size) in a PLAIN GeometryList followed by a floor cuboid; accelerate applies GeometryList::accelerate.
+Scene scene_scatter(int n, uint64_t seed, bool accelerate, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h) {
+    SplitMix64 g{seed};
+    Scene scene;
+    for (int i = 0; i < n; i++) {
+        float cx = -6.0f + 12.0f * g.uniform();
+        float cy = -6.0f + 12.0f * g.uniform();
+        float cz = 0.2f + 2.3f * g.uniform();
+        float r = 0.1f + 0.3f * g.uniform();
+        GeomPtr geom = (i % 2 == 0) ? Sphere(Vec3D(cx, cy, cz), r) : Cuboid::make(vec3d(cx - r, cy - r, cz - r), vec3d(cx + r, cy + r, cz + r));
+        Material m = (i % 3 == 0) ? Metal() : ((i % 3 == 1) ? Lambartian(COLOR_WHITE) : Lambartian(Checkerboard(4)));
+        scene.root.push(Object::with_material(geom, m));
+    }
+    if (accelerate) scene.root.accelerate(2);
+    scene.root.push(Object::with_material(Cuboid::make(vec3d(-8.0f, -8.0f, 0.0f), vec3d(8.0f, 8.0f, -1.0f)), Glossy(1e3f, 0.3f, COLOR_WHITE)));
+    Camera cam(cam_w, cam_h);
+    cam.position(Vec3D(-9.0f, -9.0f, 6.0f)).look_at(Vec3D(0.0f, 0.0f, 0.8f), -Vec3D::z_axis());
     scene.camera = cam;
     scene.skybox = skybox;
     scene.lights = main_lights();

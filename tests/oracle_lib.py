@@ -48,6 +48,10 @@ def lib():
         _lib.orc_scene_terrain.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_grid.restype = C.c_void_p
         _lib.orc_scene_grid.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.orc_scene_grid2.restype = C.c_void_p
+        _lib.orc_scene_grid2.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.orc_scene_scatter.restype = C.c_void_p
+        _lib.orc_scene_scatter.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_free.argtypes = [C.c_void_p]
         _lib.orc_scene_set_camera_size.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _lib.orc_scene_camera.argtypes = [C.c_void_p, _f32p, _u32p]
@@ -112,9 +116,15 @@ class OracleScene:
         return cls(hnd, sky)
 
     @classmethod
-    def grid(cls, nx, ny, sky=None, cam=(1080, 960), ply=BUNNY_PLY):
+    def grid(cls, nx, ny, sky=None, cam=(1080, 960), ply=BUNNY_PLY, flat=False):
         sky = procedural_sky() if sky is None else np.ascontiguousarray(sky, dtype=np.uint8)
-        hnd = lib().orc_scene_grid(ply.encode(), nx, ny, sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
+        hnd = lib().orc_scene_grid2(ply.encode(), nx, ny, int(flat), sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
+        return cls(hnd, sky)
+
+    @classmethod
+    def scatter(cls, n, seed=1, accelerate=False, sky=None, cam=(1080, 960)):
+        sky = procedural_sky() if sky is None else np.ascontiguousarray(sky, dtype=np.uint8)
+        hnd = lib().orc_scene_scatter(n, seed, int(accelerate), sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
         return cls(hnd, sky)
 
     @classmethod

@@ -1,0 +1,177 @@
+"""GPU parity at the sizes the benchmark configurations name: the 230 x 230 instanced grid (50.1 M triangles) under the
+7680x4320 camera, 10 000 spheres, the real skybox image, the flattened (world-space) grid, instances seen from far
+away, the multi-context render and the top-level tree extension.  Same bar as test_gpu_trace / test_gpu_render.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_render import compare
+from test_gpu_trace import check_closest, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def grid_pair(rt, ol, sky):
+    cam = (7680, 4320)
+    return rt.Scene.grid(230, 230, sky=sky, cam=cam).upload(0), ol.OracleScene.grid(230, 230, sky=sky, cam=cam), cam
+
+
+def test_grid_230x230_sampled_rays_bit_exact(rt, grid_pair):
+    """52 900 instances in one object tree: about 100 k primary rays of the 8K camera, 100 k incoherent rays, any-hit."""
+    gpu, cpu, cam = grid_pair
+    rays = np.concatenate([cpu.primary_rays(0, y, cam[0], 4) for y in (700, 2160, 3300)] + [cpu.primary_rays(3000, 2500, 128, 64)], axis=1)
+    rays = np.ascontiguousarray(rays)
+    assert rays.shape[1] > 100_000
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 0.3 * rays.shape[1]
+    rays = random_rays(100_000, seed=51, center=(0, 0, 2), radius=420.0)
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 1000
+    rays[6] = np.random.default_rng(9).uniform(0.0, 600.0, rays.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+    assert 0 < ref.sum() < ref.size
+
+
+def test_grid_230x230_scheduler_equals_plain_kernel(rt, grid_pair):
+    """A larger batch through both kernels (no oracle): the persistent scheduler and the plain nested loops agree bit for bit."""
+    gpu, cpu, cam = grid_pair
+    rays = np.ascontiguousarray(np.concatenate([cpu.primary_rays(0, 1800, cam[0], 96), random_rays(300_000, seed=53, center=(0, 0, 2), radius=420.0)], axis=1))
+    a = gpu.trace_closest(rays)
+    occ_a = gpu.trace_any(rays)
+    try:
+        gpu.set_option(rt.OPT_SCHEDULER, 0)
+        b = gpu.trace_closest(rays)
+        occ_b = gpu.trace_any(rays)
+    finally:
+        gpu.set_option(rt.OPT_SCHEDULER, 1)
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert np.array_equal(occ_a, occ_b)
+
+
+def test_grid_8k_sub_rectangle_render_in_chunks(rt, grid_pair):
+    """A sub-rectangle of the 7680x4320 frame against the oracle, max_paths forcing several wavefront chunks."""
+    gpu, cpu, cam = grid_pair
+    rect = (3712, 2304, 224, 144)
+    region = rt.Scene.make_region(cam[0], cam[1], rect=rect)
+    params = dict(max_depth=5, shadow_rays=1, antialiasing=2)
+    img, st = gpu.render(region=region, **params)
+    ref, _, cnt = cpu.render(rect=rect, **params)
+    compare(img, ref)
+    assert abs(st["closest_rays"] - cnt["closest_rays"]) <= 2e-3 * cnt["closest_rays"]
+    gpu.set_option(rt.OPT_MAX_PATHS, 8192)
+    try:
+        img2, _ = gpu.render(region=region, **params)
+    finally:
+        gpu.set_option(rt.OPT_MAX_PATHS, 1 << 22)
+    assert np.array_equal(img.view(np.uint32), img2.view(np.uint32))
+
+
+def test_spheres_10000(rt, ol, sky):
+    cam = (320, 240)
+    gpu = rt.Scene.spheres(n=10000, seed=1, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.spheres(n=10000, seed=1, sky=sky, cam=cam)
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays), exact_uv=False)
+    assert hits > 0.5 * rays.shape[1]
+    rays = random_rays(100_000, seed=57, center=(0, 0, 2), radius=14.0)
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays), exact_uv=False)
+    rays[6] = np.random.default_rng(4).uniform(0.0, 20.0, rays.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+    img, _ = gpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+    ref_img, _, _ = cpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+    compare(img, ref_img)
+
+
+def test_real_skybox_render(rt, ol):
+    """assets/skybox.jpg (6900 x 3450, decoded by PIL on both sides) through the miss shader: the first + y * w + x texel path."""
+    real = ol.load_skybox()
+    assert real.shape == (3450, 6900, 3)
+    cam = (240, 200)
+    gpu, cpu = rt.Scene.main(sky=real, cam=cam).upload(0), ol.OracleScene.main(sky=real, cam=cam)
+    for params in (dict(max_depth=5, shadow_rays=1, antialiasing=2), dict(max_depth=0, shadow_rays=1, antialiasing=1)):
+        img, _ = gpu.render(**params)
+        ref, _, _ = cpu.render(**params)
+        compare(img, ref)
+    assert len(np.unique((ref * 255).astype(np.uint8).reshape(-1, 3), axis=0)) > 500   # a real image, not a flat colour
+
+
+def test_flat_grid_matches_oracle(rt, ol, sky):
+    """The world-space form of the grid: every instance its own mesh and tree, the oracle built on the same arrays."""
+    cam = (320, 240)
+    gpu = rt.Scene.grid(6, 5, sky=sky, cam=cam, flat=True).upload(0)
+    cpu = ol.OracleScene.grid(6, 5, sky=sky, cam=cam, flat=True)
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 0.3 * rays.shape[1]
+    rays = random_rays(100_000, seed=61, center=(0, 0, 1), radius=16.0)
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    rays[6] = np.random.default_rng(6).uniform(0.0, 20.0, rays.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+    img, _ = gpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+    ref_img, _, _ = cpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+    compare(img, ref_img)
+
+
+def test_instances_seen_from_far_away(rt, ol, sky):
+    """Rotated instances viewed from 1e4 object sizes away: the object-box prefilter must not drop a ray that the
+    reference's own root-box test accepts once rounding at that distance exceeds the box's fixed pad."""
+    cam = (64, 48)
+    gpu = rt.Scene.grid(6, 5, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.grid(6, 5, sky=sky, cam=cam)
+    rng = np.random.default_rng(71)
+    n = 200_000
+    target = np.stack([rng.uniform(-13, 13, n), rng.uniform(-11, 11, n), rng.uniform(0.5, 3.5, n)])
+    d = rng.normal(size=(3, n))
+    d /= np.linalg.norm(d, axis=0)
+    dist = 10.0 ** rng.uniform(2.0, 4.6, n)          # up to 4e4 units: the meshes are about 3.5 units wide
+    rays = np.empty((7, n), np.float32)
+    rays[0:3] = target - d * dist
+    dd = (target - rays[0:3].astype(np.float64))
+    dd /= np.linalg.norm(dd, axis=0)
+    rays[3:6] = dd.astype(np.float32)
+    dn = np.sqrt((rays[3:6].astype(np.float64) ** 2).sum(axis=0))
+    rays[3:6] = (rays[3:6] / dn).astype(np.float32)
+    rays[6] = 1e12
+    rays = np.ascontiguousarray(rays)
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 0.2 * n
+    rays[6] = (dist * rng.uniform(0.9, 1.1, n)).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+
+
+def test_render_over_several_contexts_is_bitwise_the_single_context_frame(rt, sky):
+    """render::parallel_render over a list of devices (rtamd_render_multi): two and three contexts on GPU 0."""
+    cam = (200, 150)
+    params = dict(max_depth=4, shadow_rays=2, antialiasing=2)
+    single, st1 = rt.Scene.main(sky=sky, cam=cam).upload(0).render(**params)
+    for ids in ([0, 0], [0, 0, 0]):
+        scene = rt.Scene.main(sky=sky, cam=cam)
+        img, st = rt.render_multi(scene, ids, **params)
+        assert np.array_equal(img.view(np.uint32), single.view(np.uint32)), ids
+        assert (st["closest_rays"], st["any_rays"], st["paths"]) == (st1["closest_rays"], st1["any_rays"], st1["paths"])
+
+
+@pytest.mark.parametrize("accelerate", [False, True])
+def test_plain_list_and_its_top_level_tree(rt, ol, sky, accelerate):
+    """300 spheres / cuboids in a plain GeometryList, walked linearly as the reference does and through the top-level
+    tree extension; the oracle is built the same way in both cases."""
+    cam = (240, 180)
+    gpu = rt.Scene.scatter(300, seed=5, accelerate=accelerate, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.scatter(300, seed=5, accelerate=accelerate, sky=sky, cam=cam)
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays), exact_uv=False)
+    assert hits > 0.5 * rays.shape[1]
+    rays = random_rays(60_000, seed=67, center=(0, 0, 1), radius=9.0)
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays), exact_uv=False)
+    rays[6] = np.random.default_rng(2).uniform(0.0, 12.0, rays.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+    img, _ = gpu.render(max_depth=3, shadow_rays=1, antialiasing=2)
+    ref_img, _, _ = cpu.render(max_depth=3, shadow_rays=1, antialiasing=2)
+    compare(img, ref_img)
