@@ -6,6 +6,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -24,7 +25,7 @@ struct rtamd_context {
     std::string error;
     LaunchCfg cfg;
     bool profile = false;
-    size_t max_paths = (size_t)1 << 22;
+    size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
     // scene
     bool have_scene = false;
@@ -132,7 +133,8 @@ int convert_tree(rtamd_context* ctx, const rtamd_bvh_node* nodes, uint32_t n_nod
 // the reference's own transforms is orders of magnitude below that).  slack = 0.011 x the chain's scale: the visit test
 // of the trees lets t run 0.01 beyond the box in the object's t (bvh.rs:231), and t grows by `scale` on the way out
 // (transform.rs:104-107).
-void object_box(const rtamd_scene_desc* sc, const rtamd_object& ob, const std::vector<float4>& nodes, const std::vector<DevMesh>& meshes, DevObject& d) {
+void object_box(const rtamd_scene_desc* sc, const rtamd_object& ob, const std::vector<float4>& nodes, const std::vector<DevMesh>& meshes, DevObject& d,
+                bool zero_translate = false /* the box relative to the chain's offset: every Translate counts as zero */) {
     const float inf = std::numeric_limits<float>::infinity();
     for (int k = 0; k < 3; k++) { d.bmin[k] = -inf; d.bmax[k] = inf; }
     d.slack = inf;
@@ -154,7 +156,8 @@ void object_box(const rtamd_scene_desc* sc, const rtamd_object& ob, const std::v
     for (uint32_t q = ob.op_count; q-- > 0;) {
         const rtamd_xform_op& op = sc->ops[ob.op_first + q];
         if (op.kind == RTAMD_OP_TRANSLATE) {
-            for (int k = 0; k < 3; k++) { lo[k] += op.v[k]; hi[k] += op.v[k]; }
+            if (!zero_translate)
+                for (int k = 0; k < 3; k++) { lo[k] += op.v[k]; hi[k] += op.v[k]; }
         } else if (op.kind == RTAMD_OP_SCALE) {
             if (!(op.v[0] > 0.0f)) return;   // mirrored or degenerate: no box
             scale *= op.v[0];
@@ -540,6 +543,60 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         object_box(sc, ob, nodes, meshes, d);
         objects.push_back(d);
     }
+    // Instance records and classes (see DevInst): an object whose wrapper chain is inline (at most one Translate, Scale and
+    // Rotate each, in that order) belongs to the class of all objects with the same primitive, wrapper kinds and rotation;
+    // meshes also share the scale (the class carries the box of the scaled, rotated mesh).  An object without a Translate
+    // gets the offset +0, which leaves a position as it is bit for bit.
+    std::vector<DevObject> classes;
+    std::vector<DevInst> insts(sc->n_objects);
+    {
+        auto same_class = [](const DevObject& a, const DevObject& b) {
+            if (a.geom_kind != b.geom_kind || a.geom_index != b.geom_index || a.xf_kind != b.xf_kind) return false;
+            if ((a.xf_kind & XF_R) && std::memcmp(a.rot, b.rot, sizeof(a.rot)) != 0) return false;
+            if (a.geom_kind == GEOM_MESH && (std::memcmp(&a.scale, &b.scale, 4) != 0 || std::memcmp(&a.inv_scale, &b.inv_scale, 4) != 0)) return false;
+            return true;
+        };
+        uint32_t last = CLS_NONE;
+        for (uint32_t o = 0; o < sc->n_objects; o++) {
+            const DevObject& d = objects[o];
+            DevInst in{};
+            std::memcpy(in.off, d.off, 12);
+            in.scale = d.scale; in.inv_scale = d.inv_scale; in.cls = CLS_NONE; in.material = d.material;
+            if (!(d.xf_kind & XF_GENERIC)) {
+                DevObject key = d;
+                key.xf_kind |= XF_T;
+                key.material = 0; key.op_first = 0; key.op_count = 0; key.pad1 = 0;
+                std::memset(key.off, 0, sizeof(key.off));
+                uint32_t c = CLS_NONE;
+                if (last != CLS_NONE && same_class(classes[last], key)) c = last;
+                for (uint32_t k = 0; k < classes.size() && c == CLS_NONE; k++)
+                    if (same_class(classes[k], key)) c = k;
+                if (c == CLS_NONE && classes.size() < MAX_CLASSES) {
+                    if (key.geom_kind != GEOM_MESH) { key.scale = 1.0f; key.inv_scale = 1.0f; }
+                    if (key.xf_kind & XF_BOX) {   // the class box: this object's box with every Translate taken as zero
+                        DevObject rel{};
+                        object_box(sc, sc->objects[o], nodes, meshes, rel, true);
+                        std::memcpy(key.bmin, rel.bmin, 12); std::memcpy(key.bmax, rel.bmax, 12); key.slack = rel.slack;
+                    }
+                    c = (uint32_t)classes.size();
+                    classes.push_back(key);
+                }
+                if (c != CLS_NONE && (classes[c].xf_kind & XF_BOX)) {
+                    // box + offset is rounded on the device: the class box's pad (1e-4 of its size) must dwarf that rounding
+                    const DevObject& k = classes[c];
+                    for (int a = 0; a < 3 && c != CLS_NONE; a++) {
+                        const float reach = std::fabs(d.off[a]) + std::max(std::fabs(k.bmin[a]), std::fabs(k.bmax[a]));
+                        const float ulp = std::nextafter(reach, std::numeric_limits<float>::infinity()) - reach;
+                        const float pad = 1e-4f * (k.bmax[a] - k.bmin[a]) / 1.0002f;
+                        if (!(4.0f * ulp < pad)) c = CLS_NONE;
+                    }
+                }
+                in.cls = c;
+                last = c != CLS_NONE ? c : last;
+            }
+            insts[o] = in;
+        }
+    }
     std::vector<DevOp> ops;
     for (uint32_t k = 0; k < sc->n_ops; k++) {
         if (sc->ops[k].kind > RTAMD_OP_BOUNDS) return fail(ctx, RTAMD_E_INVALID, "unknown transform op");
@@ -630,6 +687,9 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     if ((rc = upload_vec(ctx, lights, &S.lights))) return rc;
     if ((rc = upload_vec(ctx, sky, &S.sky))) return rc;
     if ((rc = upload_vec(ctx, images, &S.images))) return rc;
+    if ((rc = upload_vec(ctx, insts, &S.insts))) return rc;
+    if ((rc = upload_vec(ctx, classes, &S.classes))) return rc;
+    S.n_classes = (uint32_t)classes.size(); S.n_trees = sc->n_trees;
     S.n_root = sc->n_root; S.n_lights = sc->n_lights; S.sky_w = sw; S.sky_h = sh;
     S.n_objects = sc->n_objects; S.n_meshes = sc->n_meshes;
     // LDS staging: of the meshes whose nodes + triangles fit in 52 KiB (two 512-thread blocks per CU), the one that
@@ -662,6 +722,16 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     {
         size_t tb = (size_t)sc->n_objects * sizeof(DevObject) + (size_t)sc->n_ops * 48 + (size_t)sc->n_cuboids * 48 + (((size_t)sc->n_root * 8 + 15) & ~(size_t)15);
         S.tab_bytes = tb <= 8192 ? (uint32_t)tb : 0u;
+    }
+    {   // large scenes: classes, cuboids, tree headers and the root list in LDS (at most 8 KiB), instance records in global memory
+        size_t mb = classes.size() * sizeof(DevObject) + (size_t)sc->n_cuboids * 48 + (size_t)sc->n_trees * 16 + (((size_t)sc->n_root * 8 + 15) & ~(size_t)15);
+        S.mid_bytes = (S.tab_bytes == 0 && !classes.empty() && mb <= 8192) ? (uint32_t)mb : 0u;
+    }
+    if (std::getenv("RTAMD_VERBOSE")) {
+        size_t classed = 0;
+        for (const DevInst& in : insts) classed += in.cls != CLS_NONE;
+        std::fprintf(stderr, "rtamd: %u objects (%zu in %zu classes), %u meshes, %zu nodes, %zu triangles; LDS mesh %d (%u B), tables %u B, mid tables %u B\n",
+                     sc->n_objects, classed, classes.size(), sc->n_meshes, nodes.size() / 2, tris.size() / 3, (int)S.lds_mesh, S.lds_bytes, S.tab_bytes, S.mid_bytes);
     }
     ctx->S = S;
     ctx->have_scene = true;
@@ -789,7 +859,7 @@ CameraDev make_camera(const rtamd_camera& cam) {
 int render_depth_first(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, size_t total_slots,
                        float* out, rtamd_stats* stats) {
     const int D = integ->max_depth > 0 ? integ->max_depth : 0;
-    const size_t cap = std::min(total_slots, ctx->max_paths);
+    const size_t cap = std::min(total_slots, std::min(ctx->max_paths, (size_t)1 << 22));   // the stack costs 80 B per slot and depth
     const size_t stack_words = (size_t)(D ? D : 1) * 20 * cap;
     int rc = ensure_batch(ctx, 256 + stack_words * 4);
     if (rc) return rc;
@@ -1093,6 +1163,16 @@ int rtamd_quantize_device(rtamd_context* ctx, const float* rgb, size_t n, uint8_
     return RTAMD_OK;
 }
 
+#ifdef RTAMD_TIMELINE
+// Timeline build only: start / dry / end stamps of the scheduler waves since the last reset (see rt_sched.h).
+int rtamd_timeline_read(rtamd_context* ctx, unsigned long long out[8], int reset) {
+    if (!ctx) return RTAMD_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, rtamd::timeline_read(out, reset));
+    return RTAMD_OK;
+}
+#endif
 #ifdef RTAMD_DIAG
 // Diagnostic build only: per-phase totals of the scheduler kernels (cycles, steps, active lanes) x 5 phases.
 int rtamd_diag_read(rtamd_context* ctx, unsigned long long out[32], int reset) {

@@ -50,6 +50,15 @@ struct DevObject {
     float bmin[3], bmax[3]; float slack; uint32_t pad1;
 };
 static_assert(sizeof(DevObject) == 128, "object record = 8 float4");
+// Instance record of an object, 32 bytes: what distinguishes the object from the others of its class.  A class is a
+// DevObject record shared by every object with the same primitive, the same wrapper kinds and the same rotation
+// (for instance all copies of one transformed mesh, or all spheres): off = 0, scale / inv_scale unused, material unused,
+// and bmin / bmax the object's padded box relative to its offset.  The scheduler kernels enter an object from its
+// instance record (one 32-byte read from global memory) and its class (LDS) instead of the 128-byte object record.
+struct DevInst { float off[3]; float scale; float inv_scale; uint32_t cls; uint32_t material; uint32_t pad; };
+static_assert(sizeof(DevInst) == 32, "instance record = 2 float4");
+static constexpr uint32_t CLS_NONE = 0xFFFFFFFFu;   // the object has no class: use its full record
+static constexpr uint32_t MAX_CLASSES = 32;
 enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8, XF_BOX = 16 /* test the object's box (bmin, bmax) before entering */ };
 struct DevRootItem { uint32_t kind, index; };
 struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t tex_kind; int32_t tex_param; };
@@ -86,6 +95,12 @@ struct DevScene {
     uint32_t n_ops, n_cuboids;
     uint32_t any_box;         // some object carries XF_BOX: rays get their reciprocal direction when they are fetched
     uint32_t tab_bytes;       // bytes of LDS for the scene tables (objects, ops, cuboids, root), 0 = keep them in global memory
+    // Large scenes (tab_bytes = 0): instance records of all objects in global memory, the classes and the small tables
+    // (cuboids, trees, root list) in LDS.  mid_bytes = 0: not available (too many classes or cuboids).
+    const DevInst* insts;
+    const DevObject* classes;
+    uint32_t n_classes, n_trees;
+    uint32_t mid_bytes;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -287,6 +302,12 @@ struct ObjHead {
     float scale, inv_scale;
 };
 struct ObjXf { f3 off; float rot[9]; };
+struct InstRec { f3 off; float scale, inv_scale; uint32_t cls; };
+__device__ __forceinline__ InstRec unpack_inst(float4 a, float4 b) {
+    InstRec r;
+    r.off = mk(a.x, a.y, a.z); r.scale = a.w; r.inv_scale = b.x; r.cls = __float_as_uint(b.y);
+    return r;
+}
 struct ObjBox { f3 mn, mx; float slack; };
 __device__ __forceinline__ ObjBox unpack_box(float4 g, float4 h) {
     ObjBox b;
@@ -319,7 +340,13 @@ __device__ __forceinline__ CuboidRec unpack_cuboid(float4 a, float4 b, float4 c)
 }
 struct GlobalTab {
     static constexpr bool small_scene = false;
+    static constexpr bool has_inst = false;
     const DevScene* S;
+    __device__ __forceinline__ DevTree tree(uint32_t i) const { return S->trees[i]; }
+    __device__ __forceinline__ InstRec inst(uint32_t) const { InstRec r; r.off = mk(0, 0, 0); r.scale = 1.f; r.inv_scale = 1.f; r.cls = CLS_NONE; return r; }
+    __device__ __forceinline__ ObjHead cls_head(uint32_t i) const { return object(i); }
+    __device__ __forceinline__ ObjXf cls_xf(uint32_t i) const { return object_xf(i); }
+    __device__ __forceinline__ ObjBox cls_box(uint32_t i) const { return object_box(i); }
     __device__ __forceinline__ ObjHead object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1], p[2]); }
     __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_xf(p[3], p[4], p[5]); }
     __device__ __forceinline__ ObjBox object_box(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_box(p[6], p[7]); }
@@ -329,6 +356,13 @@ struct GlobalTab {
 };
 struct LdsTab {
     static constexpr bool small_scene = true;   // the tables fit the LDS budget
+    static constexpr bool has_inst = false;
+    const DevScene* S;
+    __device__ __forceinline__ DevTree tree(uint32_t i) const { return S->trees[i]; }
+    __device__ __forceinline__ InstRec inst(uint32_t) const { InstRec r; r.off = mk(0, 0, 0); r.scale = 1.f; r.inv_scale = 1.f; r.cls = CLS_NONE; return r; }
+    __device__ __forceinline__ ObjHead cls_head(uint32_t i) const { return object(i); }
+    __device__ __forceinline__ ObjXf cls_xf(uint32_t i) const { return object_xf(i); }
+    __device__ __forceinline__ ObjBox cls_box(uint32_t i) const { return object_box(i); }
     lds_float4* objects;  // 8 per object
     lds_float4* ops;      // 3 per op
     lds_float4* cuboids;  // 3 per cuboid
@@ -339,6 +373,29 @@ struct LdsTab {
     __device__ __forceinline__ OpRec op(uint32_t i) const { return unpack_op(lds_load4(ops + 3 * i), lds_load4(ops + 3 * i + 1), lds_load4(ops + 3 * i + 2)); }
     __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { return unpack_cuboid(lds_load4(cuboids + 3 * i), lds_load4(cuboids + 3 * i + 1), lds_load4(cuboids + 3 * i + 2)); }
     __device__ __forceinline__ DevRootItem root(uint32_t i) const { return DevRootItem{roots[2 * i], roots[2 * i + 1]}; }
+};
+
+// Large scenes: instance records (32 bytes per object) in global memory; classes, cuboids, object-tree headers and the
+// root list in LDS; full object records and wrapper ops (objects without a class, generic chains) in global memory.
+struct MidTab {
+    static constexpr bool small_scene = false;
+    static constexpr bool has_inst = true;
+    const DevScene* S;
+    lds_float4* classes;  // 8 per class
+    lds_float4* cuboids;  // 3 per cuboid
+    __attribute__((address_space(3))) const uint32_t* trees;   // node_base, n_nodes, first_object, pad per tree
+    __attribute__((address_space(3))) const uint32_t* roots;   // kind, index pairs
+    __device__ __forceinline__ ObjHead object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1], p[2]); }
+    __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_xf(p[3], p[4], p[5]); }
+    __device__ __forceinline__ ObjBox object_box(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_box(p[6], p[7]); }
+    __device__ __forceinline__ OpRec op(uint32_t i) const { const float4* p = (const float4*)(S->ops + i); return unpack_op(p[0], p[1], p[2]); }
+    __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { return unpack_cuboid(lds_load4(cuboids + 3 * i), lds_load4(cuboids + 3 * i + 1), lds_load4(cuboids + 3 * i + 2)); }
+    __device__ __forceinline__ DevRootItem root(uint32_t i) const { return DevRootItem{roots[2 * i], roots[2 * i + 1]}; }
+    __device__ __forceinline__ DevTree tree(uint32_t i) const { return DevTree{trees[4 * i], trees[4 * i + 1], trees[4 * i + 2], 0u}; }
+    __device__ __forceinline__ InstRec inst(uint32_t i) const { const float4* p = (const float4*)(S->insts + i); return unpack_inst(p[0], p[1]); }
+    __device__ __forceinline__ ObjHead cls_head(uint32_t c) const { return unpack_object(lds_load4(classes + 8 * c), lds_load4(classes + 8 * c + 1), lds_load4(classes + 8 * c + 2)); }
+    __device__ __forceinline__ ObjXf cls_xf(uint32_t c) const { return unpack_xf(lds_load4(classes + 8 * c + 3), lds_load4(classes + 8 * c + 4), lds_load4(classes + 8 * c + 5)); }
+    __device__ __forceinline__ ObjBox cls_box(uint32_t c) const { return unpack_box(lds_load4(classes + 8 * c + 6), lds_load4(classes + 8 * c + 7)); }
 };
 
 // ------------------------------------------------------------------------------------------------

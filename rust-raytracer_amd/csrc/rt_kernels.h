@@ -130,6 +130,9 @@ hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, con
                                     int scatter_rays, uint32_t aa, uint32_t chunk_begin, uint32_t chunk_n, float* stack, uint32_t cap, float* out,
                                     unsigned long long* stats, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
+#ifdef RTAMD_TIMELINE
+hipError_t timeline_read(unsigned long long* out, int reset);
+#endif
 #ifdef RTAMD_DIAG
 hipError_t diag_read(unsigned long long* out, int reset);
 hipError_t diag_read_shade(unsigned long long* out, int reset);

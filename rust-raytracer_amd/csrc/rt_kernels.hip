@@ -80,11 +80,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene S, RayBatch 
 }
 
 // Scheduler versions of the two batch kernels (see rt_sched.h).
-// Stages the LDS-resident parts of the scene for a scheduler kernel: the small mesh (MESHLOC != GLOBAL)
-// followed by the scene tables (TAB_LDS).  LDS layout, in float4 units:
-//   [mesh nodes | mesh triangles | objects (8 each) | ops (3 each) | cuboids (3 each) | root items (uint2)]
-template <int MESHLOC, bool TAB_LDS>
-__device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, LdsTab& ltab) {
+// Stages the LDS-resident parts of the scene for a scheduler kernel: the small mesh (MESHLOC != GLOBAL) followed by the
+// scene tables.  LDS layout, in float4 units:
+//   TAB_LDS: [mesh nodes | mesh triangles | objects (8 each) | ops (3 each) | cuboids (3 each) | root items (uint2)]
+//   TAB_MID: [mesh nodes | mesh triangles | classes (8 each) | cuboids (3 each) | tree headers (uint4) | root items (uint2)]
+enum : int { TAB_GLOBAL = 0, TAB_LDS = 1, TAB_MID = 2 };
+template <int MESHLOC, int TABKIND>
+__device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, LdsTab& ltab, MidTab& mtab) {
     uint32_t base = 0;  // float4 offset
     lds.nodes = (lds_float4*)g_lds;
     lds.tris = (lds_float4*)g_lds;
@@ -99,7 +101,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         lds.tris = (lds_float4*)g_lds + n_node4;
         base = n_mesh4;
     }
-    if (TAB_LDS) {
+    if (TABKIND == TAB_LDS) {
         const uint32_t n_obj4 = 8 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
         const float4* go = (const float4*)S.objects;
         const float4* gp = (const float4*)S.ops;
@@ -109,12 +111,29 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         for (uint32_t i = threadIdx.x; i < n_cub4; i += blockDim.x) g_lds[base + n_obj4 + n_op4 + i] = gc[i];
         uint2* lr = (uint2*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
         for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
+        ltab.S = &S;
         ltab.objects = (lds_float4*)g_lds + base;
         ltab.ops = (lds_float4*)g_lds + base + n_obj4;
         ltab.cuboids = (lds_float4*)g_lds + base + n_obj4 + n_op4;
         ltab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
     }
-    if (MESHLOC != MESH_GLOBAL || TAB_LDS) __syncthreads();
+    if (TABKIND == TAB_MID) {
+        const uint32_t n_cls4 = 8 * S.n_classes, n_cub4 = 3 * S.n_cuboids, n_tree4 = S.n_trees;
+        const float4* gk = (const float4*)S.classes;
+        const float4* gc = (const float4*)S.cuboids;
+        const float4* gt = (const float4*)S.trees;
+        for (uint32_t i = threadIdx.x; i < n_cls4; i += blockDim.x) g_lds[base + i] = gk[i];
+        for (uint32_t i = threadIdx.x; i < n_cub4; i += blockDim.x) g_lds[base + n_cls4 + i] = gc[i];
+        for (uint32_t i = threadIdx.x; i < n_tree4; i += blockDim.x) g_lds[base + n_cls4 + n_cub4 + i] = gt[i];
+        uint2* lr = (uint2*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
+        for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
+        mtab.S = &S;
+        mtab.classes = (lds_float4*)g_lds + base;
+        mtab.cuboids = (lds_float4*)g_lds + base + n_cls4;
+        mtab.trees = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4);
+        mtab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
+    }
+    if (MESHLOC != MESH_GLOBAL || TABKIND != TAB_GLOBAL) __syncthreads();
 }
 
 struct BatchIO {
@@ -150,7 +169,7 @@ struct BatchIO {
     __device__ __forceinline__ void store_any(uint32_t i, uint32_t, bool occluded) const { any_out[i] = occluded ? 1 : 0; }
 };
 
-template <int MESHLOC, bool TAB_LDS>
+template <int MESHLOC, int TABKIND>
 __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
     {   // not even the block's first wave has a batch (see trace_scheduler)
         const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64), tune_min_batch(chunk));
@@ -160,10 +179,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_bat
     __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][COOP_WORDS / 2];
     LdsMesh lds;
     LdsTab ltab;
-    stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
+    MidTab mtab;
+    stage_scene<MESHLOC, TABKIND>(S, lds, ltab, mtab);
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
     lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, stage, coop);
+    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, stage, coop);
+    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC>(S, mtab, lds, io, work_head, n, chunk, stage, coop);
     else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage, coop);
 }
 
@@ -580,7 +601,7 @@ struct WaveIO {
     __device__ __forceinline__ void store_any(uint32_t i, uint32_t tag, bool occluded) const { (i >= n_a0 ? +vis1 : +vis0)[tag] = occluded ? 1 : 0; }
 };
 
-template <int MESHLOC, bool TAB_LDS>
+template <int MESHLOC, int TABKIND>
 __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
                                                             uint32_t a1_idx, uint32_t head_idx, uint32_t chunk_hint) {
     // queue lengths written by the previous stages (index MISS: that queue is absent)
@@ -605,10 +626,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trac
     lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
     LdsMesh lds;
     LdsTab ltab;
-    stage_scene<MESHLOC, TAB_LDS>(S, lds, ltab);
+    MidTab mtab;
+    stage_scene<MESHLOC, TABKIND>(S, lds, ltab, mtab);
     WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.p_ray, W.set[0].a_ray, W.set[1].a_ray, W.set[0].a_vidx, W.set[1].a_vidx, W.h_rec, W.p_rec,
               W.set[0].vis, W.set[1].vis, W.cap, W.any_cap, n_q, n_closest, n_closest + n_a0};
-    if (TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
+    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
+    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC>(S, mtab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
     else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
 }
 
@@ -1023,14 +1046,15 @@ static inline int mesh_location(const DevScene& S, const LaunchCfg& cfg) {
 }
 #define RTAMD_DISPATCH_TAB(KERNEL, ML, tab, grid, lds_bytes, st, ...)                                                          \
     do {                                                                                                                    \
-        if (tab) hipLaunchKernelGGL((KERNEL<ML, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);           \
-        else hipLaunchKernelGGL((KERNEL<ML, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);              \
+        if (tab == TAB_LDS) hipLaunchKernelGGL((KERNEL<ML, TAB_LDS>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);  \
+        else if (tab == TAB_MID) hipLaunchKernelGGL((KERNEL<ML, TAB_MID>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<ML, TAB_GLOBAL>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);         \
     } while (0)
 #define RTAMD_DISPATCH_MESHLOC(S, cfg, KERNEL, grid, st, ...)                                                                 \
     do {                                                                                                                    \
         const int loc_ = mesh_location(S, cfg);                                                                             \
-        const bool tab_ = cfg.use_lds && (S).tab_bytes > 0;                                                                  \
-        const uint32_t lb_ = (loc_ != MESH_GLOBAL ? (S).lds_bytes : 0u) + (tab_ ? (S).tab_bytes : 0u);                        \
+        const int tab_ = !cfg.use_lds ? TAB_GLOBAL : ((S).tab_bytes > 0 ? TAB_LDS : ((S).mid_bytes > 0 ? TAB_MID : TAB_GLOBAL));  \
+        const uint32_t lb_ = (loc_ != MESH_GLOBAL ? (S).lds_bytes : 0u) + (tab_ == TAB_LDS ? (S).tab_bytes : (tab_ == TAB_MID ? (S).mid_bytes : 0u)); \
         if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, grid, lb_, st, __VA_ARGS__);                         \
         else if (loc_ == MESH_MIXED) RTAMD_DISPATCH_TAB(KERNEL, MESH_MIXED, tab_, grid, lb_, st, __VA_ARGS__);                \
         else RTAMD_DISPATCH_TAB(KERNEL, MESH_GLOBAL, tab_, grid, lb_, st, __VA_ARGS__);                                       \
@@ -1143,6 +1167,17 @@ hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t
     return hipGetLastError();
 }
 
+#ifdef RTAMD_TIMELINE
+hipError_t timeline_read(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), 64);
+    if (e != hipSuccess) return e;
+    if (reset) {
+        unsigned long long z[8] = {~0ull, 0, ~0ull, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), z, 64);
+    }
+    return e;
+}
+#endif
 #ifdef RTAMD_DIAG
 hipError_t diag_read_shade(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shade_diag), 256);

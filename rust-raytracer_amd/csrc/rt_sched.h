@@ -95,6 +95,25 @@ __device__ unsigned long long g_diag[32];
 #define DIAG_FLUSH
 #endif
 
+// Timeline build only (-DRTAMD_TIMELINE): when the scheduler's waves start, run dry and end, without the per-phase probes
+// of the diagnostic build (which distort the schedule).  [0] earliest wave start, [1] latest start, [2] earliest moment a
+// wave found the queue empty, [3] latest wave end, [4] sum of wave lifetimes, [5] waves, [6] sum of lifetimes after the
+// wave's queue ran dry, [7] loop trips.
+#ifdef RTAMD_TIMELINE
+__device__ unsigned long long g_timeline[8];
+#define TL_DECL unsigned long long tl_start = __builtin_amdgcn_s_memtime(), tl_dry = 0, tl_trips = 0;
+#define TL_TRIP tl_trips++;
+#define TL_DRY if (tl_dry == 0) tl_dry = __builtin_amdgcn_s_memtime();
+#define TL_FLUSH if (lane == 0) { const unsigned long long tl_end = __builtin_amdgcn_s_memtime(); atomicMin(&g_timeline[0], tl_start); atomicMax(&g_timeline[1], tl_start); \
+        if (tl_dry) { atomicMin(&g_timeline[2], tl_dry); atomicAdd(&g_timeline[6], tl_end - tl_dry); } atomicMax(&g_timeline[3], tl_end); atomicAdd(&g_timeline[4], tl_end - tl_start); \
+        atomicAdd(&g_timeline[5], 1ull); atomicAdd(&g_timeline[7], tl_trips); }
+#else
+#define TL_DECL
+#define TL_TRIP
+#define TL_DRY
+#define TL_FLUSH
+#endif
+
 // Claims the next chunk of the work queue for the wave (one atomic per chunk).
 __device__ __forceinline__ uint32_t claim_chunk(uint32_t* work_head, uint32_t chunk) {
     uint32_t base = 0;
@@ -253,8 +272,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     };
 
     DIAG_DECL
+    TL_DECL
     for (;;) {
         DIAG_TOP
+        TL_TRIP
         // ---- vote: run the phase most lanes are waiting for ----
         const uint32_t c_tri = wave_count(st == ST_TRI);
         const uint32_t c_node = wave_count(st == ST_NODE);
@@ -408,7 +429,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                             const DevRootItem it = tab.root(root_i++);
                             if (it.kind == ROOT_OBJECT) { o_cur = it.index; o_end = it.index + 1; }
                             else {
-                                const DevTree tr = S.trees[it.index];
+                                const DevTree tr = tab.tree(it.index);
                                 t_base = tr.node_base; t_n = tr.n_nodes; t_first = tr.first_object; t_i = 0;
                                 if (!S.any_box) winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // bvh.rs:220
                                 if (t_n > 0) { fl |= F_INTREE; st = ST_TNODE; }
@@ -424,10 +445,17 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     // the object's box in the space of the ray: most rays miss most objects, and this test needs neither
                     // the wrappers nor a reciprocal direction per object.  It only ever skips what the object's own first
                     // test would turn away (the comparisons are false for NaN, so nothing is skipped on one).
-                    ObjHead ob = tab.object(oi);
+                    // Large scenes read the object's 32-byte instance record and take the rest from its class in LDS.
+                    ObjHead ob;
+                    InstRec in = tab.inst(oi);
+                    const bool classed = Tab::has_inst && in.cls != CLS_NONE;
+                    if (classed) { ob = tab.cls_head(in.cls); ob.scale = in.scale; ob.inv_scale = in.inv_scale; }
+                    else ob = tab.object(oi);
                     bool skip = false;
                     if (ob.xf_kind & XF_BOX) {
-                        const ObjBox ox = tab.object_box(oi);
+                        ObjBox ox;
+                        if (classed) { ox = tab.cls_box(in.cls); ox.mn = ox.mn + in.off; ox.mx = ox.mx + in.off; }
+                        else ox = tab.object_box(oi);
                         // The slab roots carry a rounding error of a few ulps of the largest plane distance, which for a far
                         // origin exceeds the fixed pad of the box: the interval is widened by that much before it is judged.
                         const f3 pa = (ox.mn - wpos) * winv, pb = (ox.mx - wpos) * winv;
@@ -437,7 +465,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         skip = (bt0 > bt1 + err) || (bt0 > wtmax * 1.00001f + err) || (bt1 < -err);
                     }
                     if (!skip) {
-                    const ObjXf xf = tab.object_xf(oi);   // read with the head: one LDS round trip instead of two
+                    ObjXf xf;   // read with the head: one round trip instead of two
+                    if (classed) { xf = tab.cls_xf(in.cls); xf.off = in.off; }
+                    else xf = tab.object_xf(oi);
                     opos = wpos; otmax = wtmax;
                     odir = wdir;
                     oscale = ob.scale;
@@ -533,6 +563,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     }
                     if (base >= n_items) {
                         exhausted = true;
+                        TL_DRY
                     } else {
                         chunk_next = base;
                         chunk_end = (n_items - base) < chunk ? n_items : base + chunk;
@@ -557,6 +588,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         DIAG_END(phase)
     }
     DIAG_FLUSH
+    TL_FLUSH
 }
 
 }  // namespace rtamd
