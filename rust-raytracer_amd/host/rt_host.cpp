@@ -576,6 +576,7 @@ void Device::check(int rc, const char* what) const {
 }
 
 void Scene::flatten() {
+    if (!linear_root) root.accelerate(accelerate_min);
     auto fs = std::make_shared<FlatScene>();
     auto add_material = [&](const Material& m) {
         rtamd_material flat = m.m;

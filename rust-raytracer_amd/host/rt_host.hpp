@@ -289,6 +289,11 @@ struct Device {
 
 struct Scene {  // scene.rs:8-13
     GeometryList root;
+    // Extension, on by default: when the scene is flattened, every run of at least `accelerate_min` plain objects of the
+    // root list is walked through an AABBTree<Object> built over the run (GeometryList::accelerate) instead of linearly;
+    // the reference's own scenes (4 objects) are below the threshold.  linear_root = true keeps the reference's walk.
+    bool linear_root = false;
+    size_t accelerate_min = 64;
     std::shared_ptr<const Image> skybox;
     std::vector<Light> lights;
     Camera camera = Camera(1, 1);

@@ -235,6 +235,7 @@ Scene scene_scatter(int n, uint64_t seed, bool accelerate, std::shared_ptr<const
         scene.root.push(Object::with_material(geom, m));
     }
     if (accelerate) scene.root.accelerate(2);
+    else scene.linear_root = true;   // the reference's linear walk, whatever the length of the list
     scene.root.push(Object::with_material(Cuboid::make(vec3d(-8.0f, -8.0f, 0.0f), vec3d(8.0f, 8.0f, -1.0f)), Glossy(1e3f, 0.3f, COLOR_WHITE)));
     Camera cam(cam_w, cam_h);
     cam.position(Vec3D(-9.0f, -9.0f, 6.0f)).look_at(Vec3D(0.0f, 0.0f, 0.8f), -Vec3D::z_axis());
