@@ -51,6 +51,9 @@ WORKLOADS = {
     "bunny_grid_flat_230x230_7680x4320_256spp_depth5": dict(scene=("grid_flat", 230, 230), cam=(7680, 4320), aa=16, max_depth=5, shadow_rays=1, baseline_config=4,
                                                             desc="the same 230 x 230 grid flattened to world space: 52 900 separate meshes (50.1 M world-space triangles, "
                                                                  "one tree each) in one AABBTree<Object> + floor cuboid + skybox.jpg"),
+    "bunny_grid_merged_230x230_7680x4320_256spp_depth5": dict(scene=("grid_merged", 230, 230), cam=(7680, 4320), aa=16, max_depth=5, shadow_rays=1, baseline_config=4,
+                                                              desc="the same 230 x 230 grid flattened to world space and merged by material: three meshes of 16.7 M world-space "
+                                                                   "triangles each (trees built on the GPU) + floor cuboid in a plain list + skybox.jpg"),
 }
 DEFAULT_WORKLOAD = "bunny_1080x960_64spp_depth5"
 TILE = 64
@@ -69,7 +72,7 @@ def cpu_threads():
     return max(1, min(n, 64))
 
 
-def make_scene(mod, spec, sky, cam):
+def make_scene(mod, spec, sky, cam, gpu_build=False):
     kind = spec[0]
     if kind == "main":
         return mod.main(sky=sky, cam=cam)
@@ -78,7 +81,9 @@ def make_scene(mod, spec, sky, cam):
     if kind == "grid":
         return mod.grid(spec[1], spec[2], sky=sky, cam=cam)
     if kind == "grid_flat":
-        return mod.grid(spec[1], spec[2], sky=sky, cam=cam, flat=True)
+        return mod.grid(spec[1], spec[2], sky=sky, cam=cam, flat=1)
+    if kind == "grid_merged":   # the product builds the three 16.7 M-triangle trees on the GPU, the oracle (bounded sample only) on the host
+        return mod.grid(spec[1], spec[2], sky=sky, cam=cam, flat=3 if gpu_build else 2)
     raise SystemExit(f"unknown scene {spec}")
 
 
@@ -228,7 +233,7 @@ def main():
         cam_wh = (w, int(round(world * base_wh[0] * base_wh[1] / w)))
     sky = rt.load_skybox(max_width=1024 if args.small_sky else None)
     t0 = time.perf_counter()
-    scene = make_scene(rt.Scene, wl["scene"], sky, cam_wh)
+    scene = make_scene(rt.Scene, wl["scene"], sky, cam_wh, gpu_build=True)
     host_build_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     scene.upload(dev_index)

@@ -239,6 +239,16 @@ const char* rtamd_last_error(const rtamd_context* ctx);
  * src/main.rs:39-83 for the device side. */
 int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* scene);
 
+/* AABBTree::new / with_partition + partition_sah (src/geom/bvh.rs:10-177) on the GPU: the binned-SAH tree over n
+ * primitive boxes (6 floats each: min xyz, max xyz; host memory), bit-identical to the reference's sequential builder
+ * for finite boxes (node boxes, skip links, leaf ranges and the order of the primitives inside the leaves, split-cost
+ * expression as written included).  nodes_out needs room for 2 n records (at most 2 n - 1 nodes plus the sentinel of
+ * src/geom/bvh.rs:164-165); *n_nodes_out receives the count including the sentinel; order_out[k] = index of the input
+ * box that is the k-th primitive in tree order (AABBTree::objs after construction).  For trees where the host build
+ * dominates (millions of primitives); needs no uploaded scene. */
+int rtamd_build_bvh(rtamd_context* ctx, const float* boxes, uint32_t n, float hit_cost, rtamd_bvh_node* nodes_out,
+                    uint32_t* n_nodes_out, uint32_t* order_out);
+
 /* Batched Geometry::hit on the scene root (src/geom/mod.rs:30, caller src/integrator.rs:64).
  * Host pointers; copies in and out. */
 int rtamd_trace_closest(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out);

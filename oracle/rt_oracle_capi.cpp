@@ -240,6 +240,38 @@ void* orc_scene_grid2(const char* ply_path, int nx, int ny, int flat, const uint
             }
             objs.emplace_back(flat ? GeomPtr() : GeomPtr(std::make_shared<Translate>(tmesh, V3::fill(0.0f) + off)), m);
         }
+    if (flat >= 2) {   // the instances of each material merged into one world-space mesh, in a plain root list with the floor
+        std::vector<V3> mv[3];
+        std::vector<std::array<uint32_t, 3>> mf[3];
+        for (size_t k = 0; k < objs.size(); k++) {
+            const int ix = (int)(k % (size_t)nx), iy = (int)(k / (size_t)nx), m = (ix + iy) % 3;
+            const V3 off = V3::fill(0.0f) + V3(x0 + pitch * (float)ix, y0 + pitch * (float)iy, 0.0f);
+            const uint32_t base = (uint32_t)mv[m].size();
+            for (size_t v = 0; v < verts.size(); v++) mv[m].push_back(((tb.mat.apply(verts[v]) * tb.scale_) + tb.offset) + off);
+            for (const auto& f : faces) mf[m].push_back({base + f[0], base + f[1], base + f[2]});
+        }
+        float hx = 0.5f * pitch * (float)nx + 2.0f, hy = 0.5f * pitch * (float)ny + 2.0f;
+        std::vector<std::shared_ptr<Object>> root_objs;
+        const Material mats[3] = {mat_transparent(1.0f / 0.6f), mat_metal(), mat_lambert(V3(1.f, 1.f, 1.f))};
+        for (int m = 0; m < 3; m++)
+            if (!mv[m].empty()) {
+                auto mesh = Mesh::from_vertices(mv[m], mf[m]);
+                if (root_objs.empty()) s->mesh = mesh;
+                root_objs.push_back(std::make_shared<Object>(mesh, mats[m]));
+            }
+        root_objs.push_back(std::make_shared<Object>(std::make_shared<Cuboid>(V3(-hx, -hy, bb.min[2]), V3(hx, hy, bb.min[2] - 1.0f)),
+                                                     mat_glossy(1e3f, 0.3f, V3(1.f, 1.f, 1.f))));
+        auto list = std::make_shared<GeometryList>();
+        for (auto& o : root_objs) list->items.push_back(o);
+        finalize_object_ids(s, root_objs);
+        float ext = hx > hy ? hx : hy;
+        s->cam_pos = V3(-1.2f * ext, -1.2f * ext, 0.9f * ext); s->cam_focus = V3(0.0f, 0.0f, 0.0f); s->cam_up = -V3(0.f, 0.f, 1.f);
+        s->make_camera((size_t)cam_w, (size_t)cam_h);
+        s->scene.root = list;
+        s->scene.skybox = make_sky(sky_rgb, sky_w, sky_h);
+        s->scene.lights = main_lights();
+        return s;
+    }
     if (flat) {
         std::atomic<size_t> next{0};
         auto work = [&]() {

@@ -67,7 +67,7 @@ class Stats(C.Structure):  # rtamd_stats
 ABI_SYMBOLS = (
     "rtamd_create", "rtamd_destroy", "rtamd_last_error", "rtamd_upload_scene", "rtamd_trace_closest", "rtamd_trace_any",
     "rtamd_trace_closest_device", "rtamd_trace_any_device", "rtamd_region_pixels", "rtamd_render", "rtamd_render_device",
-    "rtamd_quantize_device", "rtamd_set_option", "rtamd_kernel_times", "rtamd_trace_closest_static", "rtamd_render_multi",
+    "rtamd_quantize_device", "rtamd_set_option", "rtamd_kernel_times", "rtamd_trace_closest_static", "rtamd_render_multi", "rtamd_build_bvh",
 )
 
 
@@ -135,6 +135,7 @@ def host_lib():
         _host.rth_ply_info.argtypes = [C.c_char_p, _u32p, _f32p, _u32p, C.c_int]
         _host.rth_save_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         _host.rth_kat_reflection.argtypes = [_f32p, _f32p]
+        _host.rth_build_tree.argtypes = [C.c_int, _f32p, C.c_uint32, C.c_float, C.c_void_p, _u32p, _u32p, C.POINTER(C.c_double)]
         _host.rth_scene_free.argtypes = [C.c_void_p]
         _host.rth_scene_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
         _host.rth_scene_upload.restype = C.c_void_p
@@ -193,7 +194,9 @@ class Scene:
 
     @classmethod
     def grid(cls, nx, ny, sky=None, cam=(1080, 960), ply=BUNNY_PLY, flat=False):
-        """nx x ny instanced bunnies in an object tree; flat: every instance a world-space mesh of its own."""
+        """nx x ny instanced bunnies in an object tree; flat = 1 / True: every instance a world-space mesh of its own; flat = 2:
+        the instances of each material merged into one world-space mesh (3 meshes, plain root list), trees built on the
+        host; flat = 3: the same, trees built by the GPU builder on GPU 0."""
         sky, p, w, h = cls._sky_args(sky)
         return cls(host_lib().rth_scene_grid2(ply.encode(), nx, ny, int(flat), p, w, h, cam[0], cam[1]), sky)
 
@@ -339,6 +342,22 @@ class Scene:
         if n_tiles == 1:
             out = out[0]
         return out, st.as_dict()
+
+
+def build_tree(boxes, hit_cost=0.1, device=None):
+    """AABBTree::new over boxes[n, 6] (min xyz, max xyz): on the host (device None) or on a GPU (rtamd_build_bvh).
+    Returns (nodes[n_nodes, 8] as u32 words incl. the sentinel, order[n], seconds)."""
+    boxes = np.ascontiguousarray(boxes, np.float32)
+    n = boxes.shape[0]
+    nodes = np.zeros((2 * n + 1, 8), np.uint32)
+    order = np.zeros(n, np.uint32)
+    n_nodes = C.c_uint32()
+    sec = C.c_double()
+    rc = host_lib().rth_build_tree(-1 if device is None else device, boxes.ctypes.data_as(_f32p), n, hit_cost, nodes.ctypes.data, order.ctypes.data_as(_u32p),
+                                   C.byref(n_nodes), C.byref(sec))
+    if rc != 0:
+        raise RtamdError("build_tree failed: " + host_lib().rth_last_error().decode())
+    return nodes[:n_nodes.value], order, sec.value
 
 
 def render_multi(scene, device_ids, max_depth=5, shadow_rays=1, scatter_rays=1, antialiasing=1):

@@ -1155,6 +1155,36 @@ int rtamd_render_multi(rtamd_context* const* ctxs, int n, const rtamd_camera* ca
     return RTAMD_OK;
 }
 
+int rtamd_build_bvh(rtamd_context* ctx, const float* boxes, uint32_t n, float hit_cost, rtamd_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out) {
+    if (!ctx || !boxes || !nodes_out || !n_nodes_out || !order_out) return RTAMD_E_INVALID;
+    if (n == 0 || n > 0x3FFFFFFFu) return fail(ctx, RTAMD_E_INVALID, "rtamd_build_bvh: between 1 and 2^30 - 1 boxes");
+    for (size_t k = 0; k < (size_t)n * 6; k++)
+        if (!std::isfinite(boxes[k])) return fail(ctx, RTAMD_E_INVALID, "rtamd_build_bvh: boxes must be finite");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* d_boxes = nullptr;
+    rtamd_bvh_node* d_nodes = nullptr;
+    uint32_t* d_order = nullptr;
+    int rc = RTAMD_OK;
+    auto release = [&]() { if (d_boxes) (void)hipFree(d_boxes); if (d_nodes) (void)hipFree(d_nodes); if (d_order) (void)hipFree(d_order); };
+#define BUILD_TRY(expr)                                                                                          \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) { rc = fail(ctx, RTAMD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); release(); return rc; } \
+    } while (0)
+    BUILD_TRY(hipMalloc((void**)&d_boxes, (size_t)n * 24));
+    BUILD_TRY(hipMalloc((void**)&d_nodes, (size_t)2 * n * sizeof(rtamd_bvh_node) + sizeof(rtamd_bvh_node)));
+    BUILD_TRY(hipMalloc((void**)&d_order, (size_t)n * 4));
+    BUILD_TRY(hipMemcpyAsync(d_boxes, boxes, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t n_nodes = 0;
+    BUILD_TRY(build_bvh_device(d_boxes, n, hit_cost, d_nodes, &n_nodes, d_order, ctx->cfg.num_cus, ctx->stream));
+    BUILD_TRY(hipMemcpy(nodes_out, d_nodes, (size_t)n_nodes * sizeof(rtamd_bvh_node), hipMemcpyDeviceToHost));
+    BUILD_TRY(hipMemcpy(order_out, d_order, (size_t)n * 4, hipMemcpyDeviceToHost));
+#undef BUILD_TRY
+    *n_nodes_out = n_nodes;
+    release();
+    return RTAMD_OK;
+}
+
 int rtamd_quantize_device(rtamd_context* ctx, const float* rgb, size_t n, uint8_t* out) {
     if (!ctx || !rgb || !out) return RTAMD_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -2,6 +2,8 @@
 #pragma once
 #include "rt_device.h"
 
+struct rtamd_bvh_node;
+
 namespace rtamd {
 
 static constexpr int TRACE_BLOCK = 512;  // threads per block of the traversal kernels (8 waves)
@@ -130,6 +132,10 @@ hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, con
                                     int scatter_rays, uint32_t aa, uint32_t chunk_begin, uint32_t chunk_n, float* stack, uint32_t cap, float* out,
                                     unsigned long long* stats, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
+// The reference's binned-SAH tree over n boxes (6 floats each, device memory), built on the GPU (rt_bvh.hip).
+// nodes_out: room for 2 n records; *n_nodes_out includes the sentinel; order_out: n primitive indices in tree order.
+hipError_t build_bvh_device(const float* boxes, uint32_t n, float hit_cost, ::rtamd_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* order_out, int num_cus,
+                            hipStream_t st);
 #ifdef RTAMD_TIMELINE
 hipError_t timeline_read(unsigned long long* out, int reset);
 #endif

@@ -278,6 +278,21 @@ BvhTree build_aabb_tree(const std::vector<AABB>& boxes, float hit_cost) {
     t.order = std::move(b.order);
     return t;
 }
+BvhTree build_aabb_tree(Device& dev, const std::vector<AABB>& boxes, float hit_cost) {
+    if (boxes.empty()) return build_aabb_tree(boxes, hit_cost);
+    std::vector<float> flat(boxes.size() * 6);
+    for (size_t k = 0; k < boxes.size(); k++) {
+        flat[6 * k] = boxes[k].min.x; flat[6 * k + 1] = boxes[k].min.y; flat[6 * k + 2] = boxes[k].min.z;
+        flat[6 * k + 3] = boxes[k].max.x; flat[6 * k + 4] = boxes[k].max.y; flat[6 * k + 5] = boxes[k].max.z;
+    }
+    BvhTree t;
+    t.nodes.resize(2 * boxes.size() + 1);
+    t.order.resize(boxes.size());
+    uint32_t n_nodes = 0;
+    dev.check(rtamd_build_bvh(dev.ctx, flat.data(), (uint32_t)boxes.size(), hit_cost, t.nodes.data(), &n_nodes, t.order.data()), "rtamd_build_bvh");
+    t.nodes.resize(n_nodes);
+    return t;
+}
 void bvh_statistics(const BvhTree& t, uint32_t out[5]) {
     uint32_t n = (uint32_t)t.nodes.size(), max_leaf = 0, min_leaf = (uint32_t)t.order.size(), leafs = 0;
     for (uint32_t i = 0; i + 1 < n; i++) {
@@ -315,7 +330,7 @@ static void emit_object(FlatScene& fs, std::vector<rtamd_xform_op>& ops, uint32_
     fs.objects.push_back(o);
 }
 
-std::shared_ptr<Mesh> Mesh::from_vertices(const std::vector<Vec3D>& vertices, const std::vector<std::array<uint32_t, 3>>& faces) {
+std::shared_ptr<Mesh> Mesh::from_vertices(const std::vector<Vec3D>& vertices, const std::vector<std::array<uint32_t, 3>>& faces, Device* builder) {
     const size_t n = vertices.size();
     for (const auto& f : faces)
         for (uint32_t i : f)
@@ -337,7 +352,7 @@ std::shared_ptr<Mesh> Mesh::from_vertices(const std::vector<Vec3D>& vertices, co
     std::vector<AABB> boxes(faces.size());  // mesh.rs:149-157
     for (size_t k = 0; k < faces.size(); k++)
         boxes[k] = AABB::from_point(vertices[faces[k][0]]).union_point(vertices[faces[k][1]]).union_point(vertices[faces[k][2]]);
-    mesh->tree = build_aabb_tree(boxes, 0.1f);  // mesh.rs:50
+    mesh->tree = builder ? build_aabb_tree(*builder, boxes, 0.1f) : build_aabb_tree(boxes, 0.1f);  // mesh.rs:50
     mesh->face_of_prim = mesh->tree.order;
     for (uint32_t face : mesh->tree.order)
         mesh->tri_indices.insert(mesh->tri_indices.end(), {faces[face][0], faces[face][1], faces[face][2]});

@@ -146,6 +146,9 @@ struct BvhTree {  // result of AABBTree::new: nodes incl. sentinel + the permuta
 // Binned-SAH pre-order build with skip links: AABBTree::with_partition + partition_sah,
 // src/geom/bvh.rs:10-171 (including its split-cost expression as written).
 BvhTree build_aabb_tree(const std::vector<AABB>& boxes, float hit_cost);
+struct Device;
+// The same tree, built on the GPU (rtamd_build_bvh): identical nodes and order; worth it from some 10^5 boxes on.
+BvhTree build_aabb_tree(Device& dev, const std::vector<AABB>& boxes, float hit_cost);
 void bvh_statistics(const BvhTree& t, uint32_t out[5]);  // bvh.rs:179-204
 
 struct Mesh : Geometry, std::enable_shared_from_this<Mesh> {  // mesh.rs:16-81
@@ -153,7 +156,8 @@ struct Mesh : Geometry, std::enable_shared_from_this<Mesh> {  // mesh.rs:16-81
     std::vector<uint32_t> tri_indices;     // tree order, 3 per triangle
     std::vector<uint32_t> face_of_prim;    // original face index of each tree-order triangle
     BvhTree tree;
-    static std::shared_ptr<Mesh> from_vertices(const std::vector<Vec3D>& vertices, const std::vector<std::array<uint32_t, 3>>& faces);
+    // builder: build the tree on that GPU instead of on the host (same tree)
+    static std::shared_ptr<Mesh> from_vertices(const std::vector<Vec3D>& vertices, const std::vector<std::array<uint32_t, 3>>& faces, Device* builder = nullptr);
     // mesh.rs:83-116: vertices shared by bit pattern, numbered in order of first appearance
     static std::shared_ptr<Mesh> from_triangles(const std::vector<std::array<Vec3D, 3>>& tris);
     AABB bounding_box() const override;
@@ -340,8 +344,9 @@ std::shared_ptr<Mesh> load_ply_as_mesh(const std::string& path);
 Scene scene_main(const std::string& ply_path, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 // Synthetic scenes of the larger benchmark configurations (generator: splitmix64, see rt_scenes.cpp).
 Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
-// flat: every instance is a mesh of its own with world-space vertices (no ray transform), see rt_scenes.cpp
-Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, bool flat = false);
+// flat 1: every instance is a mesh of its own with world-space vertices (no ray transform); flat 2: the instances of each
+// of the three materials merged into one world-space mesh (its tree built on `builder` when given); see rt_scenes.cpp
+Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, int flat = 0, Device* builder = nullptr);
 // n spheres and cuboids in a plain GeometryList (the top-level extension's test scene)
 Scene scene_scatter(int n, uint64_t seed, bool accelerate, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 Scene scene_terrain(const std::string& ply_path, int n, uint64_t seed, bool with_bunny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);

@@ -1,5 +1,6 @@
 // C facade over the host library so that Python (ctypes) can drive it: build one of the scene
 // scripts, upload it to a GPU context, inspect its flattened arrays, trace and render.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -45,7 +46,15 @@ void* rth_scene_grid(const char* ply, int nx, int ny, const uint8_t* sky, int sw
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
 }
 void* rth_scene_grid2(const char* ply, int nx, int ny, int flat, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
-    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h, flat != 0); return h; });
+    // flat: 0 instanced, 1 one world-space mesh per instance, 2 / 3 one merged world-space mesh per material with its tree
+    // built on the host (2) or on GPU 0 (3)
+    return guarded([&]() -> void* {
+        auto* h = new Handle();
+        std::unique_ptr<Device> builder;
+        if (flat == 3) builder.reset(new Device(0));
+        h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h, flat >= 2 ? 2 : flat, builder.get());
+        return h;
+    });
 }
 void* rth_scene_scatter(int n, uint64_t seed, int accelerate, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_scatter(n, seed, accelerate != 0, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
@@ -168,6 +177,27 @@ int rth_render_multi(void* p, int n_ctx, const int* device_ids, const int params
         ig.max_depth = params[0]; ig.shadow_rays = params[1]; ig.scatter_rays = params[2]; ig.antialiasing = params[3];
         std::vector<float> buf = render::parallel_render(devs, h->scene, ig, stats, true);
         std::memcpy(out, buf.data(), buf.size() * 4);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+// AABBTree::new over n boxes (6 floats each) on the host (device < 0) or on GPU `device`; nodes_out: 2 n + 1 records.
+int rth_build_tree(int device, const float* boxes, uint32_t n, float hit_cost, rtamd_bvh_node* nodes_out, uint32_t* order_out, uint32_t* n_nodes_out, double* seconds) {
+    try {
+        std::vector<AABB> bx(n);
+        for (uint32_t k = 0; k < n; k++) bx[k] = AABB(Vec3D(boxes[6 * k], boxes[6 * k + 1], boxes[6 * k + 2]), Vec3D(boxes[6 * k + 3], boxes[6 * k + 4], boxes[6 * k + 5]));
+        BvhTree t;
+        std::unique_ptr<Device> dev;
+        if (device >= 0) dev.reset(new Device(device));
+        auto t0 = std::chrono::steady_clock::now();
+        t = device >= 0 ? build_aabb_tree(*dev, bx, hit_cost) : build_aabb_tree(bx, hit_cost);
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::memcpy(nodes_out, t.nodes.data(), t.nodes.size() * sizeof(rtamd_bvh_node));
+        std::memcpy(order_out, t.order.data(), t.order.size() * 4);
+        *n_nodes_out = (uint32_t)t.nodes.size();
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

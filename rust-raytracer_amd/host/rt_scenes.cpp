@@ -89,7 +89,10 @@ Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, s
 // space in f32 the way a hit point leaves the wrappers (rotate, scale, the Transform's own offset, the instance offset:
 // transform.rs:183,108,61), with its own normals and tree (Mesh::from_vertices) and no ray transform: nx * ny * 948
 // world-space triangles in nx * ny trees (230 x 230: 50.1 M triangles, 2.4 GB of triangle records).
-Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, bool flat) {
+// flat 2: the instances of each material merged into one world-space mesh (three meshes of nx * ny * 948 / 3 triangles,
+// vertices of instance k at [453 k', 453 k' + 453) in instance order) in a plain root list with the floor: no object
+// tree, no instancing; the three trees are built by `builder` (the GPU builder) when one is given.
+Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, int flat, Device* builder) {
     std::vector<Vec3D> verts;
     std::vector<std::array<uint32_t, 3>> faces;
     loader::load_ply(ply_path, verts, faces);
@@ -107,6 +110,30 @@ Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<co
             Material m = ((ix + iy) % 3 == 0) ? Transparent(1.0f / 0.6f) : (((ix + iy) % 3 == 1) ? Metal() : Lambartian(COLOR_WHITE));
             objs.push_back(Object::with_material(flat ? GeomPtr() : GeomPtr(Translate::make(tmesh)->translate(off)), m));
         }
+    if (flat == 2) {
+        std::vector<Vec3D> mv[3];
+        std::vector<std::array<uint32_t, 3>> mf[3];
+        for (size_t k = 0; k < objs.size(); k++) {
+            const int ix = (int)(k % (size_t)nx), iy = (int)(k / (size_t)nx), m = (ix + iy) % 3;
+            const Vec3D off = Vec3D::zero() + Vec3D(x0 + pitch * (float)ix, y0 + pitch * (float)iy, 0.0f);
+            const uint32_t base = (uint32_t)mv[m].size();
+            for (size_t v = 0; v < verts.size(); v++) mv[m].push_back(((tform->mat.apply(verts[v]) * tform->scale_) + tform->offset) + off);
+            for (const auto& f : faces) mf[m].push_back({base + f[0], base + f[1], base + f[2]});
+        }
+        float hx = 0.5f * pitch * (float)nx + 2.0f, hy = 0.5f * pitch * (float)ny + 2.0f;
+        Scene scene;
+        const Material mats[3] = {Transparent(1.0f / 0.6f), Metal(), Lambartian(COLOR_WHITE)};
+        for (int m = 0; m < 3; m++)
+            if (!mv[m].empty()) scene.root.push(Object::with_material(Mesh::from_vertices(mv[m], mf[m], builder), mats[m]));
+        scene.root.push(Object::with_material(Cuboid::make(vec3d(-hx, -hy, bb.min.z), vec3d(hx, hy, bb.min.z - 1.0f)), Glossy(1e3f, 0.3f, COLOR_WHITE)));
+        float ext = hx > hy ? hx : hy;
+        Camera cam(cam_w, cam_h);
+        cam.position(Vec3D(-1.2f * ext, -1.2f * ext, 0.9f * ext)).look_at(Vec3D(0.0f, 0.0f, 0.0f), -Vec3D::z_axis());
+        scene.camera = cam;
+        scene.skybox = skybox;
+        scene.lights = main_lights();
+        return scene;
+    }
     if (flat) {   // the instances' meshes, built on up to 16 host threads
         std::atomic<size_t> next{0};
         auto work = [&]() {

@@ -175,3 +175,26 @@ def test_plain_list_and_its_top_level_tree(rt, ol, sky, accelerate):
     img, _ = gpu.render(max_depth=3, shadow_rays=1, antialiasing=2)
     ref_img, _, _ = cpu.render(max_depth=3, shadow_rays=1, antialiasing=2)
     compare(img, ref_img)
+
+
+@pytest.mark.parametrize("flat", [2, 3])
+def test_merged_flat_grid_matches_oracle(rt, ol, sky, flat):
+    """The grid flattened and merged by material: three world-space meshes in a plain list, their trees built on the host
+    (2) or by the GPU builder (3); the oracle builds the same three meshes with the reference's builder."""
+    cam = (320, 240)
+    gpu = rt.Scene.grid(6, 5, sky=sky, cam=cam, flat=flat).upload(0)
+    cpu = ol.OracleScene.grid(6, 5, sky=sky, cam=cam, flat=2)
+    gn, go, gs = gpu.tree(0)
+    cn, co, cs = cpu.bvh(0)
+    assert np.array_equal(gn, cn) and np.array_equal(go, co) and gs[0] == 10 * 948   # the first merged mesh: 10 of the 30 instances
+    rays = cpu.primary_rays(0, 0, cam[0], cam[1])
+    hits = check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    assert hits > 0.3 * rays.shape[1]
+    rays = random_rays(100_000, seed=73, center=(0, 0, 1), radius=16.0)
+    check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
+    rays[6] = np.random.default_rng(6).uniform(0.0, 20.0, rays.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(rays)
+    assert np.array_equal(gpu.trace_any(rays), ref)
+    img, _ = gpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+    ref_img, _, _ = cpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+    compare(img, ref_img)
