@@ -173,3 +173,16 @@ def test_quantizer_matches(rt, ol, pair):
     rc = rt.rtamd_lib().rtamd_quantize_device(gpu.ctx, d.data_ptr(), d.numel(), out.data_ptr())
     assert rc == 0
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_pixels_are_those_of_the_pinned_gpu_frames(rt, ol, sky):
+    """tests/golden/gpu_frames.npz holds frames rendered by an earlier build of the wavefront pipeline (tools/make_gpu_golden.py):
+    changes to the launch structure must leave every pixel bit-identical (same order of every radiance sum)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_gpu_golden
+    pinned = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpu_frames.npz"))
+    for name, scene, params in make_gpu_golden.frames(rt, sky):
+        img, _ = scene.upload(0).render(**params)
+        assert np.array_equal(img.view(np.uint32), pinned[name].view(np.uint32)), name
