@@ -11,6 +11,10 @@ static constexpr int STAGE_BLOCK = 1024; // threads per block of the queue-build
 #ifndef RTAMD_SCHED_WAVES
 #define RTAMD_SCHED_WAVES 4
 #endif
+#ifndef RTAMD_NOMESH_WAVES
+#define RTAMD_NOMESH_WAVES 6
+#endif
+static constexpr int NOMESH_WAVES_PER_SIMD = RTAMD_NOMESH_WAVES;  // scheduler kernels of scenes without meshes: three 8-wave blocks per CU, 80 VGPRs
 static constexpr int SCHED_WAVES_PER_SIMD = RTAMD_SCHED_WAVES;  // register budget of the scheduler kernels: two 8-wave blocks per CU = 4 waves/SIMD, 128 VGPRs
 
 struct RayBatch { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };

@@ -90,7 +90,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
     uint32_t base = 0;  // float4 offset
     lds.nodes = (lds_float4*)g_lds;
     lds.tris = (lds_float4*)g_lds;
-    if (MESHLOC != MESH_GLOBAL) {
+    if (MESHLOC == MESH_LDS || MESHLOC == MESH_MIXED) {
         const DevMesh m = S.meshes[S.lds_mesh];
         const uint32_t n_node4 = 2 * m.n_nodes;
         const uint32_t n_mesh4 = S.lds_bytes / 16;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         mtab.trees = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4);
         mtab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
     }
-    if (MESHLOC != MESH_GLOBAL || TABKIND != TAB_GLOBAL) __syncthreads();
+    if (MESHLOC == MESH_LDS || MESHLOC == MESH_MIXED || TABKIND != TAB_GLOBAL) __syncthreads();
 }
 
 struct BatchIO {
@@ -170,7 +170,7 @@ struct BatchIO {
 };
 
 template <int MESHLOC, int TABKIND>
-__global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
+__global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
     {   // not even the block's first wave has a batch (see trace_scheduler)
         const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64), tune_min_batch(chunk));
         if (blockIdx.x >= (n + bs - 1u) / bs) return;
@@ -602,7 +602,7 @@ struct WaveIO {
 };
 
 template <int MESHLOC, int TABKIND>
-__global__ __launch_bounds__(TRACE_BLOCK, SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
+__global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
                                                             uint32_t a1_idx, uint32_t head_idx, uint32_t chunk_hint) {
     // queue lengths written by the previous stages (index MISS: that queue is absent)
     const uint32_t n_q = q_idx == MISS ? 0u : W.counts[q_idx];
@@ -1033,14 +1033,16 @@ static inline uint32_t trace_grid(const LaunchCfg& cfg, size_t n) {
     return (uint32_t)(g ? g : 1);
 }
 
-static inline uint32_t sched_grid(const LaunchCfg& cfg, size_t upper) {
+static inline uint32_t sched_grid(const LaunchCfg& cfg, size_t upper, bool no_mesh = false) {
     size_t need = (upper + TRACE_BLOCK - 1) / TRACE_BLOCK;
-    size_t cap = (size_t)cfg.num_cus * cfg.sched_blocks_per_cu;
+    // scenes without meshes run the leaner kernel instance at a higher occupancy: half as many blocks again per CU
+    size_t cap = (size_t)cfg.num_cus * (no_mesh ? (cfg.sched_blocks_per_cu * NOMESH_WAVES_PER_SIMD + SCHED_WAVES_PER_SIMD - 1) / SCHED_WAVES_PER_SIMD : cfg.sched_blocks_per_cu);
     size_t g = need < cap ? need : cap;
     return (uint32_t)(g ? g : 1);
 }
 // Which template instance a launch needs: all mesh trees staged in LDS, none, or a mix.
 static inline int mesh_location(const DevScene& S, const LaunchCfg& cfg) {
+    if (S.n_meshes == 0) return MESH_NONE;
     if (!cfg.use_lds || S.lds_mesh == MISS) return MESH_GLOBAL;
     return S.n_meshes == 1 ? MESH_LDS : MESH_MIXED;
 }
@@ -1054,8 +1056,9 @@ static inline int mesh_location(const DevScene& S, const LaunchCfg& cfg) {
     do {                                                                                                                    \
         const int loc_ = mesh_location(S, cfg);                                                                             \
         const int tab_ = !cfg.use_lds ? TAB_GLOBAL : ((S).tab_bytes > 0 ? TAB_LDS : ((S).mid_bytes > 0 ? TAB_MID : TAB_GLOBAL));  \
-        const uint32_t lb_ = (loc_ != MESH_GLOBAL ? (S).lds_bytes : 0u) + (tab_ == TAB_LDS ? (S).tab_bytes : (tab_ == TAB_MID ? (S).mid_bytes : 0u)); \
-        if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, grid, lb_, st, __VA_ARGS__);                         \
+        const uint32_t lb_ = ((loc_ == MESH_LDS || loc_ == MESH_MIXED) ? (S).lds_bytes : 0u) + (tab_ == TAB_LDS ? (S).tab_bytes : (tab_ == TAB_MID ? (S).mid_bytes : 0u)); \
+        if (loc_ == MESH_NONE) RTAMD_DISPATCH_TAB(KERNEL, MESH_NONE, tab_, grid, lb_, st, __VA_ARGS__);                       \
+        else if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, grid, lb_, st, __VA_ARGS__);                    \
         else if (loc_ == MESH_MIXED) RTAMD_DISPATCH_TAB(KERNEL, MESH_MIXED, tab_, grid, lb_, st, __VA_ARGS__);                \
         else RTAMD_DISPATCH_TAB(KERNEL, MESH_GLOBAL, tab_, grid, lb_, st, __VA_ARGS__);                                       \
     } while (0)
@@ -1073,7 +1076,7 @@ hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const R
     if (cfg.scheduler) {
         hipError_t e = hipMemsetAsync(work_head, 0, 4, st);
         if (e != hipSuccess) return e;
-        uint32_t g = sched_grid(cfg, n);
+        uint32_t g = sched_grid(cfg, n, S.n_meshes == 0);
         BatchIO io{S, rays, out, nullptr, false};
         uint32_t chunk = sched_chunk(cfg, n, g);
         RTAMD_DISPATCH_MESHLOC(S, cfg, k_trace_batch_sched, g, st, S, io, (uint32_t)n, work_head, chunk);
@@ -1090,7 +1093,7 @@ hipError_t launch_trace_any(const DevScene& S, const LaunchCfg& cfg, const RayBa
     if (cfg.scheduler) {
         hipError_t e = hipMemsetAsync(work_head, 0, 4, st);
         if (e != hipSuccess) return e;
-        uint32_t g = sched_grid(cfg, n);
+        uint32_t g = sched_grid(cfg, n, S.n_meshes == 0);
         BatchIO io{S, rays, HitBatch{nullptr, nullptr, nullptr, nullptr, nullptr}, out, true};
         uint32_t chunk = sched_chunk(cfg, n, g);
         RTAMD_DISPATCH_MESHLOC(S, cfg, k_trace_batch_sched, g, st, S, io, (uint32_t)n, work_head, chunk);
@@ -1116,7 +1119,7 @@ hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hip
 }
 hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
                              uint32_t a1_idx, uint32_t head_idx, size_t upper, hipStream_t st) {
-    uint32_t g = sched_grid(cfg, upper);
+    uint32_t g = sched_grid(cfg, upper, S.n_meshes == 0);
     RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, p_idx, a0_idx, a1_idx, head_idx,
                            (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20));
     return hipGetLastError();

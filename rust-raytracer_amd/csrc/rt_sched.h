@@ -35,7 +35,9 @@ struct LdsMesh {
     lds_float4* tris;
 };
 // Where the mesh trees of a launch live: decided on the host per scene.
-enum : int { MESH_GLOBAL = 0, MESH_LDS = 1, MESH_MIXED = 2 };
+// MESH_NONE: the scene has no mesh at all (spheres, cuboids, triangles only): the mesh phases are compiled out, which
+// frees enough registers for a higher occupancy (see NOMESH_WAVES_PER_SIMD).
+enum : int { MESH_GLOBAL = 0, MESH_LDS = 1, MESH_MIXED = 2, MESH_NONE = 3 };
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -277,8 +279,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         DIAG_TOP
         TL_TRIP
         // ---- vote: run the phase most lanes are waiting for ----
-        const uint32_t c_tri = wave_count(st == ST_TRI);
-        const uint32_t c_node = wave_count(st == ST_NODE);
+        const uint32_t c_tri = MESHLOC != MESH_NONE ? wave_count(st == ST_TRI) : 0u;
+        const uint32_t c_node = MESHLOC != MESH_NONE ? wave_count(st == ST_NODE) : 0u;
         const uint32_t c_tnode = wave_count(st == ST_TNODE);
         const uint32_t c_obj = wave_count(st == ST_OBJ);
         const uint32_t c_fetch = wave_count(st == ST_FETCH);
@@ -296,7 +298,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         key = max(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);
         const uint32_t phase = key & 7u;
 
-        if (phase == ST_TRI) {
+        if (MESHLOC != MESH_NONE && phase == ST_TRI) {
           // Cooperative triangle phase.  A leaf of the reference's trees holds many triangles (7-30 in
           // the bunny), and the lanes waiting here are a minority of the wave, so one lane per ray
           // would test them one by one with most of the wave idle.  Instead the pending (ray, triangle)
@@ -379,7 +381,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 st = hit_a ? ST_FETCH : (mesh_done ? ST_OBJ : ST_NODE);
             }
           }
-        } else if (phase == ST_NODE) {
+        } else if (MESHLOC != MESH_NONE && phase == ST_NODE) {
           for (uint32_t c = c_node; c * NODE_STAY_DEN >= c_node * NODE_STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
             if (st == ST_NODE) node_step();
@@ -410,7 +412,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             DIAG_SUB_BEGIN
             if (st == ST_OBJ) {
                 // (1) fold a finished mesh walk into the ray's closest hit (bvh.rs:262-264, transform.rs:107)
-                if ((fl & (F_PEND | F_FOUND)) == (F_PEND | F_FOUND)) {
+                if (MESHLOC != MESH_NONE && (fl & (F_PEND | F_FOUND)) == (F_PEND | F_FOUND)) {
                     best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
                     wtmax = otmax * oscale;
                     if (fl & F_GENXF) { const ObjHead ob = tab.object(oi); wtmax = ops_t_out(tab, ob.op_first, ob.op_count, otmax); }
@@ -482,7 +484,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     }
                     DIAG_SUB_END(4)
                     DIAG_SUB_MARK
-                    if (ob.geom_kind == GEOM_MESH) {
+                    if (MESHLOC != MESH_NONE && ob.geom_kind == GEOM_MESH) {
                         n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
                         if (MESHLOC == MESH_MIXED) fl = (ob.geom_index == S.lds_mesh) ? (fl | F_MLDS) : (fl & ~F_MLDS);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
