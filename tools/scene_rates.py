@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--cam", default="1080x960")
     ap.add_argument("--scenes", default="", help="comma-separated subset of the scene names")
     ap.add_argument("--reps", type=int, default=1)
+    ap.add_argument("--scatter", type=int, default=1, help="scatter_rays (other than 1: the depth-first kernel)")
+    ap.add_argument("--depth", type=int, default=5)
     args = ap.parse_args()
     rt = entry.load_package()
     w, h = map(int, args.cam.split("x"))
@@ -40,10 +42,10 @@ def main():
         s = make()
         t_build = time.perf_counter() - t0
         s.upload(0)
-        s.render(max_depth=5, shadow_rays=1, antialiasing=1)
+        s.render(max_depth=args.depth, shadow_rays=1, scatter_rays=args.scatter, antialiasing=1)
         best = None
         for _ in range(args.reps):
-            _, st = s.render(max_depth=5, shadow_rays=1, antialiasing=args.spp_root)
+            _, st = s.render(max_depth=args.depth, shadow_rays=1, scatter_rays=args.scatter, antialiasing=args.spp_root)
             if best is None or st["device_ms"] < best["device_ms"]:
                 best = st
         st = best
