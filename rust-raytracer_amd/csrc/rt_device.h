@@ -205,6 +205,22 @@ __device__ __forceinline__ bool tri_test(float4 q0, float4 q1, float4 q2, f3 pos
     return t >= 0.0f && t <= t_max && u >= 0.0f && v >= 0.0f && u + v <= 1.0f;
 }
 
+// tri_test without control flow: the same operations in the same order, with the near-parallel case selected at the
+// end instead of branched around (the quotient of that case is computed and dropped).  For code that tests several
+// triangles at once and wants their instruction streams interleaved.
+__device__ __forceinline__ bool tri_test_flat(float4 q0, float4 q1, float4 q2, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
+    const f3 a = mk(q0.x, q0.y, q0.z), ab = mk(q0.w, q1.x, q1.y), ac = mk(q1.z, q1.w, q2.x);
+    const f3 pv = cross(dir, ac);
+    const float det = dot(ab, pv);
+    const bool flat = fabsf(det) < 1e-12f;
+    const float inv_det = 1.0f / det;
+    const f3 tv = pos - a;
+    const f3 qv = cross(tv, ab);
+    const float tt = dot(qv, ac) * inv_det, uu = dot(tv, pv) * inv_det, vv = dot(qv, dir) * inv_det;
+    t = flat ? 0.0f : tt; u = flat ? 0.0f : uu; v = flat ? 0.0f : vv;
+    return (t >= 0.0f) & (t <= t_max) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f);
+}
+
 // AABBTree<MeshTriangle>::hit / is_hit (src/geom/bvh.rs:207-281): stackless skip-link walk in the
 // reference's fixed left-first order.  Closest: t_max shrinks on every accepted triangle, a later
 // triangle with the same t replaces an earlier one (`t <= t_max`).  Any: constant t_max, first

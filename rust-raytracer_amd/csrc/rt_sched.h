@@ -72,6 +72,7 @@ static constexpr uint32_t NODE_STAY_NUM = RTAMD_NODE_STAY_NUM, NODE_STAY_DEN = R
 #endif
 static constexpr uint32_t VOTE_MESH_MIN = RTAMD_VOTE_MESH_MIN;
 static constexpr uint32_t VOTE_W[5] = {RTAMD_VOTE_W};
+static constexpr uint32_t VOTE_W_OTHER_MAX = (VOTE_W[2] > VOTE_W[3] ? (VOTE_W[2] > VOTE_W[4] ? VOTE_W[2] : VOTE_W[4]) : (VOTE_W[3] > VOTE_W[4] ? VOTE_W[3] : VOTE_W[4]));
 static constexpr uint32_t VOTE_W_TRI = VOTE_W[0], VOTE_W_NODE = VOTE_W[1], VOTE_W_OBJ = VOTE_W[2], VOTE_W_FETCH = VOTE_W[3], VOTE_W_TNODE = VOTE_W[4];
 
 // Diagnostic build only (-DRTAMD_DIAG): per-phase cycle, step and active-lane totals of the scheduler,
@@ -275,30 +276,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
 
     DIAG_DECL
     TL_DECL
-    for (;;) {
-        DIAG_TOP
-        TL_TRIP
-        // ---- vote: run the phase most lanes are waiting for ----
-        const uint32_t c_tri = MESHLOC != MESH_NONE ? wave_count(st == ST_TRI) : 0u;
-        const uint32_t c_node = MESHLOC != MESH_NONE ? wave_count(st == ST_NODE) : 0u;
-        const uint32_t c_tnode = wave_count(st == ST_TNODE);
-        const uint32_t c_obj = wave_count(st == ST_OBJ);
-        const uint32_t c_fetch = wave_count(st == ST_FETCH);
-        if ((c_tri | c_node | c_tnode | c_obj | c_fetch) == 0) break;  // every lane is ST_DONE
-        // most lanes wins; ties go to the deeper phase (the state codes grow with depth)
-        // The mesh phases always get their weight in a small scene (its tables fit LDS): the rays walk few objects
-        // in much the same order, so the mesh walks of a wave coincide.  In a scene of thousands of instances the
-        // rays are scattered over them, and running a handful of mesh lanes first would serialise the wave: there
-        // the weight applies only while at least VOTE_MESH_MIN lanes are in a mesh walk.
-        const bool mesh_first = Tab::small_scene || c_tri + c_node >= VOTE_MESH_MIN;
-        uint32_t key = ((c_tri * (mesh_first ? VOTE_W_TRI : 1u)) << 3) | ST_TRI;
-        key = max(key, ((c_node * (mesh_first ? VOTE_W_NODE : 1u)) << 3) | ST_NODE);
-        key = max(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
-        key = max(key, ((c_obj * VOTE_W_OBJ) << 3) | ST_OBJ);
-        key = max(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);
-        const uint32_t phase = key & 7u;
-
-        if (MESHLOC != MESH_NONE && phase == ST_TRI) {
+    auto tri_phase = [&]() {
           // Cooperative triangle phase.  A leaf of the reference's trees holds many triangles (7-30 in
           // the bunny), and the lanes waiting here are a minority of the wave, so one lane per ray
           // would test them one by one with most of the wave idle.  Instead the pending (ray, triangle)
@@ -322,47 +300,83 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             const uint32_t kbase = k_cur - off;                                // triangle of pair p: kbase + p
             slot[lane] = ~0ull;
-            for (uint32_t base = 0; base < total; base += 64u) {
-                DIAG_STEP(ST_TRI, (total - base < 64u ? total - base : 64u))
-                // who owns pair p = base + lane: owners mark their first pair of this round, a max-scan spreads the mark
+            // One round = 64 pairs, one per lane.  Who owns pair p = base + lane: owners mark their first pair of the round,
+            // a max-scan spreads the mark.
+            auto owner_of = [&](const uint32_t base) -> uint32_t {
                 mark[lane] = 0u;
                 const uint32_t lo = off > base ? off : base;
                 if (is_tri && lo < off + cnt && lo < base + 64u) mark[lo - base] = lane + 1u;
-                const uint32_t owner1 = wave_scan_max(mark[lane]);
+                return wave_scan_max(mark[lane]);
+            };
+            struct Pair { uint32_t o, k, tri_off; bool valid, in_lds; f3 pos, dir; float tmax; };
+            // the owner's ray and leaf position, pulled over to the lane that tests the pair
+            auto pull_pair = [&](const uint32_t base, const uint32_t owner1) -> Pair {
+                Pair P;
                 const uint32_t p = base + lane;
-                const bool valid = p < total;
-                const uint32_t o = valid ? owner1 - 1u : 0u;
-                // the owner's ray and leaf position
-                const uint32_t k = lane_pull(o, kbase) + p;
-                const f3 p_pos = mk(lane_pull(o, opos.x), lane_pull(o, opos.y), lane_pull(o, opos.z));
-                const f3 p_dir = mk(lane_pull(o, odir.x), lane_pull(o, odir.y), lane_pull(o, odir.z));
-                const float p_tmax = lane_pull(o, otmax);
-                bool p_lds = MESHLOC == MESH_LDS;
-                uint32_t p_tri_off = 0;
+                P.valid = p < total;
+                P.o = P.valid ? owner1 - 1u : 0u;
+                const uint32_t k = lane_pull(P.o, kbase) + p;
+                P.k = P.valid ? k : 0u;     // lanes without a pair read triangle 0 of a mesh and drop the result
+                P.pos = mk(lane_pull(P.o, opos.x), lane_pull(P.o, opos.y), lane_pull(P.o, opos.z));
+                P.dir = mk(lane_pull(P.o, odir.x), lane_pull(P.o, odir.y), lane_pull(P.o, odir.z));
+                P.tmax = lane_pull(P.o, otmax);
+                P.in_lds = MESHLOC == MESH_LDS;
+                P.tri_off = 0;
                 if (MESHLOC != MESH_LDS) {
-                    p_tri_off = lane_pull(o, tri_off);
-                    if (MESHLOC == MESH_MIXED) p_lds = (lane_pull(o, fl) & F_MLDS) != 0u;
+                    P.tri_off = lane_pull(P.o, tri_off);
+                    if (MESHLOC == MESH_MIXED) P.in_lds = (lane_pull(P.o, fl) & F_MLDS) != 0u;
                 }
-                float t = 0.f, u = 0.f, v = 0.f;
-                bool hit = false;
-                if (valid) {
-                    float4 q0, q1, q2;
-                    if (p_lds) {
-                        lds_float4* tp = lds.tris + 3 * k;
-                        q0 = lds_load4(tp); q1 = lds_load4(tp + 1);
-                        // only ac.z of the third quad is needed (the rest are vertex ids for the shade stage)
-                        q2 = make_float4(((__attribute__((address_space(3))) const float*)tp)[8], 0.f, 0.f, 0.f);
-                    } else {
-                        const float4* tp = S.tris + 3 * ((size_t)p_tri_off + k);
-                        q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
-                    }
-                    hit = tri_test(q0, q1, q2, p_pos, p_dir, p_tmax, t, u, v);
+                return P;
+            };
+            auto load_tri = [&](const Pair& P, float4& q0, float4& q1, float4& q2) {
+                if (P.in_lds) {
+                    lds_float4* tp = lds.tris + 3 * P.k;
+                    q0 = lds_load4(tp); q1 = lds_load4(tp + 1);
+                    // only ac.z of the third quad is needed (the rest are vertex ids for the shade stage)
+                    q2 = make_float4(((__attribute__((address_space(3))) const float*)tp)[8], 0.f, 0.f, 0.f);
+                } else {
+                    const float4* tp = S.tris + 3 * ((size_t)P.tri_off + P.k);
+                    q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
                 }
+            };
+            auto commit = [&](const Pair& P, const bool hit, const float t, const float u, const float v) {
                 // accepted t is >= 0 (or -0): its bit pattern orders like its value once -0 is folded onto +0
                 const uint32_t t_key = (t == 0.0f) ? 0u : __float_as_uint(t);
-                const unsigned long long my_key = ((unsigned long long)t_key << 32) | (unsigned long long)(0xFFFFFFFFu - k);
-                if (hit) __hip_atomic_fetch_min((lds_u64*)(coop + 64) + o, my_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (hit && slot[o] == my_key) { pay[o] = __float_as_uint(t); pay[64 + o] = __float_as_uint(u); pay[128 + o] = __float_as_uint(v); }
+                const unsigned long long my_key = ((unsigned long long)t_key << 32) | (unsigned long long)(0xFFFFFFFFu - P.k);
+                if (hit) {
+                    __hip_atomic_fetch_min((lds_u64*)(coop + 64) + P.o, my_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (slot[P.o] == my_key) { pay[P.o] = __float_as_uint(t); pay[64 + P.o] = __float_as_uint(u); pay[128 + P.o] = __float_as_uint(v); }
+                }
+            };
+            // Two rounds at a time while more than 64 pairs are left: their tests are independent instruction streams,
+            // which the SIMD issues at nearly twice the rate of one dependent chain.
+            uint32_t base = 0;
+            for (; base + 64u < total; base += 128u) {
+                DIAG_STEP(ST_TRI, 64u)
+                DIAG_STEP(ST_TRI, (total - base - 64u < 64u ? total - base - 64u : 64u))
+                const uint32_t own0 = owner_of(base);
+                const uint32_t own1 = owner_of(base + 64u);
+                const Pair P0 = pull_pair(base, own0), P1 = pull_pair(base + 64u, own1);
+                float4 a0, a1, a2, b0, b1, b2;
+                load_tri(P0, a0, a1, a2);
+                load_tri(P1, b0, b1, b2);
+                float t0, u0, v0, t1, u1, v1;
+                const bool h0 = tri_test_flat(a0, a1, a2, P0.pos, P0.dir, P0.tmax, t0, u0, v0) & P0.valid;
+                const bool h1 = tri_test_flat(b0, b1, b2, P1.pos, P1.dir, P1.tmax, t1, u1, v1) & P1.valid;
+                // both tests are complete before the first result is committed (the commit is control flow, which the
+                // instruction scheduler does not move code across)
+                asm volatile("" : "+v"(t0), "+v"(u0), "+v"(v0), "+v"(t1), "+v"(u1), "+v"(v1));
+                commit(P0, h0, t0, u0, v0);
+                commit(P1, h1, t1, u1, v1);
+            }
+            if (base < total) {
+                DIAG_STEP(ST_TRI, (total - base < 64u ? total - base : 64u))
+                const Pair P0 = pull_pair(base, owner_of(base));
+                float4 a0, a1, a2;
+                load_tri(P0, a0, a1, a2);
+                float t0, u0, v0;
+                const bool h0 = tri_test_flat(a0, a1, a2, P0.pos, P0.dir, P0.tmax, t0, u0, v0) & P0.valid;
+                commit(P0, h0, t0, u0, v0);
             }
             // owners: take the result; the leaf is done: i += 1 (bvh.rs:245)
             if (is_tri) {
@@ -381,12 +395,60 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 st = hit_a ? ST_FETCH : (mesh_done ? ST_OBJ : ST_NODE);
             }
           }
-        } else if (MESHLOC != MESH_NONE && phase == ST_NODE) {
-          for (uint32_t c = c_node; c * NODE_STAY_DEN >= c_node * NODE_STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
+    };
+    auto node_phase = [&](const uint32_t c_first) {
+          for (uint32_t c = c_first; c * NODE_STAY_DEN >= c_first * NODE_STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
             if (st == ST_NODE) node_step();
           }
-        } else if (phase == ST_TNODE) {
+    };
+    for (;;) {
+        DIAG_TOP
+        TL_TRIP
+        // ---- vote: run the phase most lanes are waiting for ----
+        const uint32_t c_tri = MESHLOC != MESH_NONE ? wave_count(st == ST_TRI) : 0u;
+        const uint32_t c_node = MESHLOC != MESH_NONE ? wave_count(st == ST_NODE) : 0u;
+        const uint32_t c_tnode = wave_count(st == ST_TNODE);
+        const uint32_t c_obj = wave_count(st == ST_OBJ);
+        const uint32_t c_fetch = wave_count(st == ST_FETCH);
+        if ((c_tri | c_node | c_tnode | c_obj | c_fetch) == 0) break;  // every lane is ST_DONE
+        // most lanes wins; ties go to the deeper phase (the state codes grow with depth)
+        // The mesh phases always get their weight in a small scene (its tables fit LDS): the rays walk few objects
+        // in much the same order, so the mesh walks of a wave coincide.  In a scene of thousands of instances the
+        // rays are scattered over them, and running a handful of mesh lanes first would serialise the wave: there
+        // the weight applies only while at least VOTE_MESH_MIN lanes are in a mesh walk.
+        const bool mesh_first = Tab::small_scene || c_tri + c_node >= VOTE_MESH_MIN;
+        uint32_t key = ((c_tri * (mesh_first ? VOTE_W_TRI : 1u)) << 3) | ST_TRI;
+        key = max(key, ((c_node * (mesh_first ? VOTE_W_NODE : 1u)) << 3) | ST_NODE);
+        key = max(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
+        key = max(key, ((c_obj * VOTE_W_OBJ) << 3) | ST_OBJ);
+        key = max(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);
+        const uint32_t phase = key & 7u;
+
+        if (MESHLOC != MESH_NONE && (phase == ST_TRI || phase == ST_NODE)) {
+          // The two mesh phases alternate many times between two steps of any other phase, and they change only a few of
+          // the lane's registers.  They run in a loop of their own, which is left when the full vote could pick another
+          // phase: inside it the rest of the lane state is loop-invariant (no copies at the loop's joins) and the vote
+          // counts two states instead of five.  The sequence of phases is the one the full vote would produce.
+          uint32_t ph = phase, cn = c_node;
+          for (;;) {
+            if (ph == ST_TRI) tri_phase(); else node_phase(cn);
+            const uint32_t ct2 = wave_count(st == ST_TRI);
+            cn = wave_count(st == ST_NODE);
+            const bool mf = Tab::small_scene || ct2 + cn >= VOTE_MESH_MIN;
+            const uint32_t kt = ct2 * (mf ? VOTE_W_TRI : 1u), kn = cn * (mf ? VOTE_W_NODE : 1u);
+            const uint32_t others = (64u - ct2 - cn) * VOTE_W_OTHER_MAX;   // upper bound of any other phase's key
+            const uint32_t km = kt >= kn ? kt : kn;
+            if (km == 0u || km < others) break;   // equal keys go to the deeper phase: a mesh phase
+            DIAG_END(ph)
+            DIAG_TOP
+            TL_TRIP
+            ph = kt >= kn ? ST_TRI : ST_NODE;
+          }
+          DIAG_END(ph)
+          continue;
+        }
+        if (phase == ST_TNODE) {
           for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * TNODE_STAY_NUM && c > 0; c = wave_count(st == ST_TNODE)) {
             DIAG_STEP(ST_TNODE, c)
             if (st == ST_TNODE) {
@@ -534,6 +596,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             }
             DIAG_SUB_END(2) }
             fl &= want ? ~F_HAVE : ~0u;
+            { DIAG_SUB_BEGIN
             if (got) {
                 bool any;
                 ridx = sg_base + sg_pos + rank;
@@ -546,8 +609,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 fl = any ? F_ANY : 0u;
                 st = ST_OBJ;
             }
+            DIAG_SUB_END(6) }
             sg_pos += take;
             // staged batch used up: request the next one now, it is read in a later FETCH step
+            { DIAG_SUB_BEGIN
             if (sg_pos == sg_cnt && !exhausted) {
                 if (chunk_next == chunk_end && ks < k_static) {  // next batch of the static deal
                     const uint64_t b = ((uint64_t)wave_id + (uint64_t)ks * n_waves) * bs;
@@ -585,6 +650,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     for (int c = 0; c < 8; c++) stage_row(src[c], stage_lds + (uint32_t)c * 256u);
                 }
             }
+            DIAG_SUB_END(7) }
             if (st == ST_FETCH && exhausted && sg_cnt == 0) st = ST_DONE;
         }
         DIAG_END(phase)
