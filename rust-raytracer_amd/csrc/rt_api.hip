@@ -25,6 +25,7 @@ struct rtamd_context {
     std::string error;
     LaunchCfg cfg;
     bool profile = false;
+    bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
     // scene
@@ -396,6 +397,7 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
             ctx->max_paths = (size_t)value;
             return RTAMD_OK;
         case RTAMD_OPT_LDS_SCENE: ctx->cfg.use_lds = value != 0; return RTAMD_OK;
+        case RTAMD_OPT_DEPTH_FIRST_ROUNDS: ctx->df_rounds = value != 0; return RTAMD_OK;
         case RTAMD_OPT_SCHEDULER: ctx->cfg.scheduler = value != 0; return RTAMD_OK;
         case RTAMD_OPT_CHUNK:
             if (value < 64 || value > 4096 || (value & (value - 1))) return fail(ctx, RTAMD_E_INVALID, "chunk must be a power of two in [64, 4096]");
@@ -844,6 +846,7 @@ int rtamd_trace_any(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_
 }
 
 namespace {
+constexpr size_t PathFrame_WORDS = 20;   // words of a path frame of the depth-first integrators (rt_kernels.hip)
 CameraDev make_camera(const rtamd_camera& cam) {
     CameraDev C;
     C.pos = f3{cam.pos[0], cam.pos[1], cam.pos[2]};
@@ -895,6 +898,81 @@ int render_depth_first(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_
     }
     return RTAMD_OK;
 }
+
+// scatter_rays != 1 on chunks that fill the GPU: the same per-pixel operation sequence as render_depth_first, run as
+// rounds of (one scheduler-kernel launch over every pixel's next ray) + (one step of every pixel's coroutine); see
+// k_df_step.  The host reads the number of active pixels back every few rounds to know when the chunk is finished.
+int render_depth_first_rounds(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, size_t total_slots,
+                              uint32_t S_total, uint32_t S_shoot, float* out, rtamd_stats* stats) {
+    typedef CounterSlots CS;
+    const int D = integ->max_depth;
+    // the frame stack costs 80 B per slot and depth: at most 6 GiB of it
+    size_t cap = std::min(total_slots, ctx->max_paths);
+    cap = std::min(cap, std::max<size_t>(65536, ((size_t)6 << 30) / ((size_t)D * PathFrame_WORDS * 4)));
+    const size_t stack_bytes = (size_t)D * PathFrame_WORDS * cap * 4;
+    int rc = ensure_batch(ctx, stack_bytes);
+    if (rc) return rc;
+    if (ctx->ws.empty()) ctx->ws.resize(1);
+    rtamd_context::Workspace& ws = ctx->ws[0];
+    rc = ensure_wave(ctx, ws, cap, S_total);
+    if (rc) return rc;
+    WaveBufs W = ws.W;
+    W.cap = (uint32_t)ws.cap;
+    hipStream_t st = ws.stream;
+    DfFrame F{make_region(*region), make_camera(*cam), (uint32_t)integ->antialiasing, D, integ->shadow_rays, integ->scatter_rays, S_shoot,
+              (float*)ctx->batch_buf, out};
+    hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
+    HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ev0, 0));
+    HIP_TRY(ctx, hipMemsetAsync(W.stats, 0, 32, st));
+    uint64_t launches = 0;
+    for (size_t begin = 0; begin < total_slots; begin += cap) {
+        const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
+        const size_t upper = (size_t)chunk_n * (1 + S_shoot);
+        HIP_TRY(ctx, hipMemsetAsync(W.counts, 0, CS::WORDS * 4, st));
+        HIP_TRY(ctx, launch_df_begin(W, F, (uint32_t)begin, chunk_n, 0u, st));
+        launches++;
+        uint32_t next_check = 8;
+        for (uint32_t r = 0;; r++) {
+            const uint32_t in = (r % 3u) * CS::TOTAL, nxt = ((r + 1u) % 3u) * CS::TOTAL, zero = ((r + 2u) % 3u) * CS::TOTAL;
+            timed_begin(ctx, 0, st);
+            HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, r & 1u, in + CS::Q, MISS, in + CS::ANY, MISS, in + CS::HEAD, upper, st));
+            timed_end(ctx, st);
+            timed_begin(ctx, 2, st);
+            HIP_TRY(ctx, launch_df_step(ctx->S, ctx->cfg, W, F, (uint32_t)begin, r & 1u, in, nxt, zero, chunk_n, st));
+            timed_end(ctx, st);
+            launches += 2;
+            if (r + 1u == next_check) {
+                uint32_t n_active = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&n_active, W.counts + nxt + CS::Q + 1, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                if (n_active == 0) break;
+                // the last pixels standing leave rounds that are nearly empty: look more often then
+                next_check = r + 1u + ((uint64_t)n_active * 64u < chunk_n ? 2u : 8u);
+            }
+        }
+    }
+    uint64_t hstats[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(hstats, W.stats, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(ws.done, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ws.done, 0));
+    HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    ctx->event_pool.push_back(ev0);
+    ctx->event_pool.push_back(ev1);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->closest_rays = hstats[0];
+        stats->any_rays = hstats[1];
+        stats->paths = owned_pixels(*region) * (uint64_t)integ->antialiasing * integ->antialiasing;
+        stats->launches = launches;
+        stats->device_ms = ms;
+    }
+    timed_collect(ctx, stats);
+    return RTAMD_OK;
+}
 }  // namespace
 
 size_t rtamd_region_pixels(const rtamd_region* region) {
@@ -924,7 +1002,12 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     const size_t total_slots = rtamd_region_pixels(region);
     if (total_slots == 0) return RTAMD_OK;
     if (total_slots > 0xFFFFFFF0ull) return fail(ctx, RTAMD_E_INVALID, "region too large");
-    if (integ->scatter_rays != 1) return render_depth_first(ctx, cam, integ, region, total_slots, out, stats);
+    if (integ->scatter_rays != 1) {
+        // the round pipeline needs a ray per pixel to start with (max_depth >= 1); RTAMD_OPT_DEPTH_FIRST_ROUNDS = 0 selects
+        // the one-lane-per-pixel kernel
+        if (ctx->df_rounds && integ->max_depth >= 1) return render_depth_first_rounds(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
+        return render_depth_first(ctx, cam, integ, region, total_slots, out, stats);
+    }
     // pixel groups: at most n_streams in flight, none smaller than 64 Ki pixels unless the region is
     const size_t G = (size_t)ctx->n_streams;
     size_t cap = (total_slots + G - 1) / G;

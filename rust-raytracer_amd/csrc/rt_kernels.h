@@ -135,6 +135,23 @@ hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk
 hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, const RegionDev& R, const CameraDev& cam, int max_depth, int shadow_rays,
                                     int scatter_rays, uint32_t aa, uint32_t chunk_begin, uint32_t chunk_n, float* stack, uint32_t cap, float* out,
                                     unsigned long long* stats, hipStream_t st);
+// The depth-first integrator as a pipeline of rounds (any scatter_rays, max_depth >= 1): every pixel of the chunk runs
+// until it needs a closest-hit ray, one launch_wave_trace per round serves all of them.  Round r: launch_wave_trace over
+// the queues of counter set r % 3 (q_idx = base + Q, a0_idx = base + ANY, head = base + HEAD, cur = r & 1), then
+// launch_df_step(cur = r & 1, in = that set, out = the next, zero = the one after).  The frame is finished when a set's
+// active count (base + Q + 1) is zero.  stack: max_depth * 20 * cap floats.
+struct DfFrame {
+    RegionDev R;
+    CameraDev cam;
+    uint32_t aa;
+    int32_t max_depth, shadow_rays, scatter_rays;
+    uint32_t n_shoot;   // shadow rays per lit hit
+    float* stack;
+    float* out;
+};
+hipError_t launch_df_begin(const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t out_base, hipStream_t st);
+hipError_t launch_df_step(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t cur, uint32_t in_base,
+                          uint32_t out_base, uint32_t zero_base, size_t upper, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 // The reference's binned-SAH tree over n boxes (6 floats each, device memory), built on the GPU (rt_bvh.hip).
 // nodes_out: room for 2 n records; *n_nodes_out includes the sentinel; order_out: n primitive indices in tree order.

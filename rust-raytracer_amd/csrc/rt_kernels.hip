@@ -1015,6 +1015,266 @@ __global__ __launch_bounds__(256) void k_pixel_depth_first(DevScene S, RegionDev
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same depth-first integrator as a pipeline of rounds, for chunks large enough to fill the GPU.  A pixel's rays are
+// inherently sequential (one random stream per pixel, and the number of draws a subtree takes depends on what its rays
+// hit), but the pixels are independent: every pixel is a coroutine that runs until it needs the result of a closest-hit
+// ray, suspends with that ray in a queue, and all suspended pixels' rays are traced by ONE launch of the scheduler
+// kernel (k_wave_trace), which is an order of magnitude faster per ray than the nested loops of k_pixel_depth_first.
+// The shadow rays of a hit do not suspend the pixel: illumination() (integrator.rs:107-132) draws all its light samples
+// before the scatter direction, visibility only enters `color = diffuse * illum`, so the samples are kept, their rays
+// ride with the pixel's next closest-hit ray, and the frame's colour is completed when the pixel resumes.  Only where
+// that colour is needed at once (no scatter ray left, or a child that ends at the depth limit without a ray) does the
+// pixel wait one round on its shadow rays alone.  Operation order per pixel is that of k_pixel_depth_first, so both
+// produce the same bits.
+//
+// Per pixel slot (arrays of the wavefront workspace, reused): random stream, running pixel sum (W.sum), a suspended
+// return value (W.Lb[0]), the pending hit's diffuse colour (W.beta) and light samples (set 0: smp = t_max, ill.xyz per
+// sample; vis), meta word (W.p_pix: x = sample pass, y = depth | state << 8 | (pending depth + 1) << 16), index of its
+// ray in the round's queue (W.p_slot).  Queues, double buffered by round parity: active pixels (W.q_slot), closest-hit
+// rays (W.q_ray -> W.h_rec); shadow rays in set 0.  Counters: three sets of CounterSlots::TOTAL in rotation, round r
+// reads set r % 3 (Q + 1 = active pixels, Q = closest-hit rays, ANY = shadow rays, HEAD = the trace launch's queue
+// head), appends to the next and zeroes the one after.
+// ------------------------------------------------------------------------------------------------
+struct DfParams {
+    RegionDev R;
+    CameraDev cam;
+    uint32_t chunk_begin, aa;
+    int32_t max_depth, shadow_rays, scatter_rays;
+    uint32_t n_shoot;
+    float* stack;   // max_depth * PathFrame::WORDS * cap
+    float* out;
+};
+enum : uint32_t { DF_ENTER = 0, DF_SCATTER = 1, DF_FOLD = 2 };
+
+__global__ __launch_bounds__(STAGE_BLOCK) void k_df_begin(WaveBufs W, DfParams X, uint32_t chunk_n, uint32_t out_base) {
+    __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
+    typedef CounterSlots CS;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cx = 0, cy = 0;
+    const bool valid = i < chunk_n && slot_pixel(X.R, X.chunk_begin + i, cx, cy);
+    uint32_t base, cnt;
+    const uint32_t q = block_append_range<STAGE_BLOCK / 64>(valid, &W.counts[out_base + CS::Q + 1], &W.counts[out_base + CS::Q], 1u, sh_app, base, cnt);
+    if (valid) {
+        const Rng r = rng_seed((uint64_t)cx ^ __builtin_bswap64((uint64_t)cy));  // integrator.rs:36
+        W.rng_lo[i] = r.lo; W.rng_hi[i] = r.hi;
+        W.sum[i] = 0.0f; W.sum[i + W.cap] = 0.0f; W.sum[i + 2 * W.cap] = 0.0f;
+        W.p_pix[i] = make_uint2(0u, 0u | (DF_ENTER << 8));
+        W.p_slot[i] = q;
+        W.q_slot[0][q] = i;
+        const f3 dir = primary_dir(X.cam, cx, cy, 0u, 0u, X.aa);
+        float* o = W.q_ray[0];
+        const uint32_t cap = W.cap;
+        o[q] = X.cam.pos.x; o[q + cap] = X.cam.pos.y; o[q + 2 * cap] = X.cam.pos.z;
+        o[q + 3 * cap] = dir.x; o[q + 4 * cap] = dir.y; o[q + 5 * cap] = dir.z;
+    } else if (i < chunk_n) {
+        const size_t o = 3 * (size_t)(X.chunk_begin + i);
+        X.out[o] = 0.0f; X.out[o + 1] = 0.0f; X.out[o + 2] = 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(STAGE_BLOCK) void k_df_step(DevScene S, WaveBufs W, DfParams X, uint32_t cur, uint32_t in_base, uint32_t out_base, uint32_t zero_base) {
+    __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
+    typedef CounterSlots CS;
+    const uint32_t n = W.counts[in_base + CS::Q + 1];
+    if (blockIdx.x == 0)   // nothing reads or appends to that set before this launch is over
+        for (uint32_t k = threadIdx.x; k < CS::TOTAL; k += blockDim.x) W.counts[zero_base + k] = 0u;
+    const uint32_t cap = W.cap;
+    const size_t ac = W.any_cap;
+    const uint32_t* act_in = W.q_slot[cur];
+    uint32_t* act_out = W.q_slot[cur ^ 1u];
+    const float* r_in = W.q_ray[cur];
+    float* r_out = W.q_ray[cur ^ 1u];
+    const ShadeSet T = W.set[0];
+    float* ret_buf = W.Lb[0];
+    const float n_scatter = (float)X.scatter_rays;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_iter = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < n_iter; it++) {
+        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool active = i < n;
+        uint32_t slot = 0, pass = 0, pend = 0;
+        int d = 0;
+        Rng rng; rng.lo = 0; rng.hi = 0;
+        PathFrame f;
+        f.color = f.w = f.n = f.dir = f.p_out = f.p_in = fill(0.0f); f.mat = 0; f.k = 0;
+        f3 ret = fill(0.0f), rpos = fill(0.0f), rdir = mk(0, 0, 1), diffuse = fill(0.0f), p_lit = fill(0.0f);
+        bool lit = false, in_scatter = false, in_return = false;
+        if (active) {
+            slot = act_in[i];
+            const uint2 meta = W.p_pix[slot];
+            pass = meta.x;
+            d = (int)(meta.y & 0xFFu);
+            const uint32_t state = (meta.y >> 8) & 0xFFu;
+            const uint32_t pend_in = meta.y >> 16;
+            rng.lo = W.rng_lo[slot]; rng.hi = W.rng_hi[slot];
+            if (pend_in) {   // the shadow rays of the pixel's last hit are back: illumination(), integrator.rs:107-132, then :87
+                const f3 df = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
+                f3 illum = fill(0.0f);
+                uint32_t s = 0;
+                for (uint32_t l = 0; l < S.n_lights; l++) {
+                    const DevLight lt = S.lights[l];
+                    const int ns = light_is_delta(lt) ? 1 : X.shadow_rays;
+                    f3 tot = fill(0.0f);
+                    for (int k = 0; k < ns; k++, s++) {
+                        const float* q = T.smp + (size_t)s * 4 * cap + slot;
+                        const bool visible = (q[0] == 0.0f) || (T.vis[(size_t)s * cap + slot] == 0);   // integrator.rs:124
+                        if (visible) tot = tot + mk(q[cap], q[2 * (size_t)cap], q[3 * (size_t)cap]);
+                    }
+                    illum = illum + tot / (float)ns;
+                }
+                const f3 c = fill(0.0f) + df * illum;
+                float* q = X.stack + (size_t)(pend_in - 1u) * PathFrame::WORDS * cap + slot;
+                q[0] = c.x; q[cap] = c.y; q[2 * (size_t)cap] = c.z;
+            }
+            if (state == DF_ENTER) {               // the closest-hit ray of integrate_recur(ray, d) is back, integrator.rs:64
+                const uint32_t qi = W.p_slot[slot];
+                rpos = mk(r_in[qi], r_in[qi + cap], r_in[qi + 2 * cap]);
+                rdir = mk(r_in[qi + 3 * cap], r_in[qi + 4 * cap], r_in[qi + 5 * cap]);
+                const uint4 rec0 = W.h_rec[2 * (size_t)qi];
+                if (rec0.x == MISS) {              // integrator.rs:66
+                    ret = sky_color(S, rdir);
+                    in_return = true;
+                } else {
+                    Best b;
+                    b.obj = rec0.x; b.prim = rec0.y;
+                    b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = __uint_as_float(W.h_rec[2 * (size_t)qi + 1].x);
+                    f3 hp, hn;
+                    float hu, hv;
+                    reconstruct_hit(S, b, rpos, rdir, hp, hn, hu, hv);
+                    f.mat = S.objects[b.obj].material;
+                    f.n = normalize(hn);
+                    const bool outside = dot(f.n, -rdir) > 0.0f;
+                    f.p_out = hp + f.n * 0.001f;
+                    f.p_in = hp - f.n * 0.001f;
+                    f.dir = rdir;
+                    f.color = fill(0.0f);
+                    f.k = 0;
+                    p_lit = outside ? f.p_out : f.p_in;
+                    diffuse = material_diffuse(S, S.materials[f.mat], hu, hv);
+                    lit = !is_zero(diffuse);       // integrator.rs:80
+                    in_scatter = true;
+                }
+            } else {
+                frame_load(X.stack, cap, slot, d, f);
+                if (state == DF_FOLD) {            // a scatter ray's radiance waited for this frame's colour, integrator.rs:98
+                    ret = mk(ret_buf[slot], ret_buf[slot + cap], ret_buf[slot + 2 * cap]);
+                    f.color = f.color + (f.w * ret) / n_scatter;
+                }
+                in_scatter = true;
+            }
+        }
+        // every lit hit emits the same number of shadow rays, so their queue positions follow from the block's range
+        uint32_t lbase, lcnt;
+        const uint32_t lq = block_append_range<STAGE_BLOCK / 64>(lit, &W.counts[out_base + CS::LIT], &W.counts[out_base + CS::ANY], X.n_shoot, sh_app, lbase, lcnt);
+        if (lit) {
+            pend = (uint32_t)d + 1u;
+            W.beta[slot] = diffuse.x; W.beta[slot + cap] = diffuse.y; W.beta[slot + 2 * cap] = diffuse.z;
+            uint32_t s = 0, s_shoot = 0;
+            for (uint32_t l = 0; l < S.n_lights; l++) {
+                const DevLight lt = S.lights[l];
+                const int ns = light_is_delta(lt) ? 1 : X.shadow_rays;
+                const bool shoots = light_shoots(lt);
+                for (int k = 0; k < ns; k++, s++) {
+                    f3 sd, ill;
+                    float tm;
+                    light_sample(lt, p_lit, f.n, rng, sd, tm, ill);
+                    float* q = T.smp + (size_t)s * 4 * cap + slot;
+                    q[0] = tm; q[cap] = ill.x; q[2 * (size_t)cap] = ill.y; q[3 * (size_t)cap] = ill.z;
+                    if (shoots) {   // (a sample with t_max = 0 is queued as a zero-length ray; the resolve takes it as visible either way)
+                        const size_t aq = (size_t)lbase * X.n_shoot + (size_t)s_shoot * lcnt + (lq - lbase);
+                        float* a = T.a_ray;
+                        a[aq] = p_lit.x; a[aq + ac] = p_lit.y; a[aq + 2 * ac] = p_lit.z;
+                        a[aq + 3 * ac] = sd.x; a[aq + 4 * ac] = sd.y; a[aq + 5 * ac] = sd.z;
+                        a[aq + 6 * ac] = tm;
+                        T.a_vidx[aq] = s * cap + slot;
+                        s_shoot++;
+                    } else {
+                        T.vis[(size_t)s * cap + slot] = 0;
+                    }
+                }
+            }
+        }
+        // run the pixel until it needs a ray, waits for its shadow rays, or is finished
+        bool want_ray = false, done = false;
+        uint32_t new_state = DF_ENTER;
+        if (active) {
+            for (;;) {
+                if (in_scatter) {                                   // integrator.rs:90-102
+                    in_scatter = false;
+                    bool descend = false;
+                    while (f.k < X.scatter_rays) {
+                        f.k++;
+                        f3 o, w;
+                        if (material_scatter(S.materials[f.mat], f.n, f.dir, rng, o, w)) {
+                            f.w = w;
+                            rpos = dot(o, f.n) > 0.0f ? f.p_out : f.p_in;
+                            rdir = o;
+                            descend = true;
+                            break;
+                        }
+                    }
+                    if (descend) {
+                        frame_store(X.stack, cap, slot, d, f);
+                        d++;
+                        if (d < X.max_depth) { want_ray = true; new_state = DF_ENTER; break; }
+                        ret = sky_color(S, rdir);                   // integrator.rs:59-61: the depth limit ends the path without a ray
+                        in_return = true;
+                    } else {
+                        if (pend == (uint32_t)d + 1u) { frame_store(X.stack, cap, slot, d, f); new_state = DF_SCATTER; break; }
+                        ret = f.color;
+                        in_return = true;
+                    }
+                }
+                if (in_return) {                                    // the call at depth d returned `ret`
+                    in_return = false;
+                    if (d == 0) {                                   // integrator.rs:50-53: next sample of the pixel
+                        f3 total = mk(W.sum[slot], W.sum[slot + cap], W.sum[slot + 2 * cap]);
+                        total = total + ret;
+                        pass++;
+                        if (pass < X.aa * X.aa) {
+                            W.sum[slot] = total.x; W.sum[slot + cap] = total.y; W.sum[slot + 2 * cap] = total.z;
+                            uint32_t cx = 0, cy = 0;
+                            (void)slot_pixel(X.R, X.chunk_begin + slot, cx, cy);
+                            rpos = X.cam.pos;
+                            rdir = primary_dir(X.cam, cx, cy, pass / X.aa, pass % X.aa, X.aa);
+                            want_ray = true; new_state = DF_ENTER;
+                        } else {
+                            total = total / (float)(X.aa * X.aa);
+                            const size_t o = 3 * (size_t)(X.chunk_begin + slot);
+                            X.out[o] = total.x; X.out[o + 1] = total.y; X.out[o + 2] = total.z;
+                            done = true;
+                        }
+                        break;
+                    }
+                    d--;
+                    if (pend == (uint32_t)d + 1u) {                 // that frame's colour is still waiting for its shadow rays
+                        ret_buf[slot] = ret.x; ret_buf[slot + cap] = ret.y; ret_buf[slot + 2 * cap] = ret.z;
+                        new_state = DF_FOLD;
+                        break;
+                    }
+                    frame_load(X.stack, cap, slot, d, f);
+                    f.color = f.color + (f.w * ret) / n_scatter;
+                    in_scatter = true;
+                }
+            }
+        }
+        const bool still = active && !done;
+        const uint32_t ai = block_append<STAGE_BLOCK / 64>(still, &W.counts[out_base + CS::Q + 1], sh_app);
+        const uint32_t qi = block_append<STAGE_BLOCK / 64>(want_ray, &W.counts[out_base + CS::Q], sh_app);
+        if (still) {
+            act_out[ai] = slot;
+            W.p_pix[slot] = make_uint2(pass, (uint32_t)d | (new_state << 8) | (pend << 16));
+            W.rng_lo[slot] = rng.lo; W.rng_hi[slot] = rng.hi;
+        }
+        if (want_ray) {
+            W.p_slot[slot] = qi;
+            r_out[qi] = rpos.x; r_out[qi + cap] = rpos.y; r_out[qi + 2 * cap] = rpos.z;
+            r_out[qi + 3 * cap] = rdir.x; r_out[qi + 4 * cap] = rdir.y; r_out[qi + 5 * cap] = rdir.z;
+        }
+    }
+}
+
 __global__ void k_quantize(const float* rgb, size_t n, uint8_t* out) {  // src/render.rs:62-72
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1161,6 +1421,23 @@ hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, con
                                 chunk_n, stack, cap, out, stats);
     else hipLaunchKernelGGL(k_pixel_depth_first<false>, dim3(g), dim3(256), 0, st, S, R, cam, max_depth, shadow_rays, scatter_rays, aa, chunk_begin,
                             chunk_n, stack, cap, out, stats);
+    return hipGetLastError();
+}
+hipError_t launch_df_begin(const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t out_base, hipStream_t st) {
+    if (chunk_n == 0) return hipSuccess;
+    const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out};
+    const uint32_t g = (chunk_n + STAGE_BLOCK - 1) / STAGE_BLOCK;
+    hipLaunchKernelGGL(k_df_begin, dim3(g), dim3(STAGE_BLOCK), 0, st, W, X, chunk_n, out_base);
+    return hipGetLastError();
+}
+hipError_t launch_df_step(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t cur, uint32_t in_base,
+                          uint32_t out_base, uint32_t zero_base, size_t upper, hipStream_t st) {
+    const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out};
+    size_t need = (upper + STAGE_BLOCK - 1) / STAGE_BLOCK;
+    size_t capg = (size_t)cfg.num_cus * (2048 / STAGE_BLOCK);
+    uint32_t g = (uint32_t)(need < capg ? need : capg);
+    if (!g) g = 1;
+    hipLaunchKernelGGL(k_df_step, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, X, cur, in_base, out_base, zero_base);
     return hipGetLastError();
 }
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st) {

@@ -81,6 +81,27 @@ def test_branching_scatter_rays_match_oracle(rt, pair, params):
         assert np.array_equal(image.view(np.uint32), img.view(np.uint32))
 
 
+@pytest.mark.parametrize("params", [
+    dict(max_depth=5, shadow_rays=1, scatter_rays=2, antialiasing=2),
+    dict(max_depth=3, shadow_rays=2, scatter_rays=3, antialiasing=1),
+    dict(max_depth=1, shadow_rays=1, scatter_rays=2, antialiasing=2),   # every scatter ray ends at the depth limit
+    dict(max_depth=4, shadow_rays=1, scatter_rays=0, antialiasing=1),
+])
+def test_depth_first_rounds_equal_the_one_lane_kernel(rt, pair, params):
+    """scatter_rays != 1 has two forms: rounds of one scheduler launch over every pixel's next ray (default) and one lane
+    per pixel with nested loops.  Same operations per pixel in the same order: same bits, same ray counts."""
+    gpu, _, _ = pair
+    img, st = gpu.render(**params)
+    gpu.set_option(rt.OPT_DEPTH_FIRST_ROUNDS, 0)
+    try:
+        ref, st0 = gpu.render(**params)
+    finally:
+        gpu.set_option(rt.OPT_DEPTH_FIRST_ROUNDS, 1)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert (st["closest_rays"], st["any_rays"]) == (st0["closest_rays"], st0["any_rays"])
+    assert st["launches"] > st0["launches"]
+
+
 def test_tiles_equal_full_frame_bitwise(rt, pair):
     """Any tile decomposition yields identical pixels: the seed depends only on (cx, cy)."""
     gpu, _, cam = pair

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--scatter", type=int, default=1, help="scatter_rays (other than 1: the depth-first kernel)")
     ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--df-rounds", type=int, default=1, help="scatter_rays != 1: 1 round pipeline, 0 one lane per pixel")
     args = ap.parse_args()
     rt = entry.load_package()
     w, h = map(int, args.cam.split("x"))
@@ -42,6 +43,7 @@ def main():
         s = make()
         t_build = time.perf_counter() - t0
         s.upload(0)
+        s.set_option(rt.OPT_DEPTH_FIRST_ROUNDS, args.df_rounds)
         s.render(max_depth=args.depth, shadow_rays=1, scatter_rays=args.scatter, antialiasing=1)
         best = None
         for _ in range(args.reps):
@@ -50,7 +52,7 @@ def main():
                 best = st
         st = best
         rays = st["closest_rays"] + st["any_rays"]
-        print(f"{name:26s} host build {t_build:6.2f} s  rays {rays:>11d}  device {st['device_ms']:8.2f} ms  {rays / st['device_ms'] / 1e3:8.1f} Mrays/s", flush=True)
+        print(f"{name:26s} host build {t_build:6.2f} s  rays {rays:>11d}  device {st['device_ms']:8.2f} ms  {rays / st['device_ms'] / 1e3:8.1f} Mrays/s  launches {st['launches']}", flush=True)
 
 
 if __name__ == "__main__":
