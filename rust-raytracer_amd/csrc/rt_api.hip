@@ -25,6 +25,7 @@ struct rtamd_context {
     std::string error;
     LaunchCfg cfg;
     bool profile = false;
+    bool deepen = true;      // object-tree walks with a growing t_max limit (exact; see rt_sched.h)
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
@@ -398,6 +399,7 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
             return RTAMD_OK;
         case RTAMD_OPT_LDS_SCENE: ctx->cfg.use_lds = value != 0; return RTAMD_OK;
         case RTAMD_OPT_DEPTH_FIRST_ROUNDS: ctx->df_rounds = value != 0; return RTAMD_OK;
+        case RTAMD_OPT_TREE_DEEPENING: ctx->deepen = value != 0; ctx->S.deepen = ctx->deepen ? 1u : 0u; return RTAMD_OK;
         case RTAMD_OPT_SCHEDULER: ctx->cfg.scheduler = value != 0; return RTAMD_OK;
         case RTAMD_OPT_CHUNK:
             if (value < 64 || value > 4096 || (value & (value - 1))) return fail(ctx, RTAMD_E_INVALID, "chunk must be a power of two in [64, 4096]");
@@ -496,7 +498,11 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         dt.node_base = (uint32_t)(nodes.size() / 2);
         dt.n_nodes = tr.n_nodes ? tr.n_nodes - 1 : 0;
         dt.first_object = tr.first_object;
-        dt.pad = 0;
+        // walks in passes of growing reach pay where entering an object is expensive (a mesh walk), not for trees of
+        // spheres or cuboids, whose objects cost less than a repeated descent from the root
+        uint32_t n_mesh = 0;
+        for (uint32_t k = 0; k < tr.n_objects; k++) n_mesh += sc->objects[tr.first_object + k].geom_kind == RTAMD_GEOM_MESH ? 1u : 0u;
+        dt.deepen = (tr.n_nodes >= 257u && 2u * (uint64_t)n_mesh >= tr.n_objects) ? 1u : 0u;
         if ((rc = convert_tree(ctx, tr.nodes, tr.n_nodes, tr.n_objects, "object tree", nodes))) return rc;
         trees.push_back(dt);
     }
@@ -735,6 +741,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         std::fprintf(stderr, "rtamd: %u objects (%zu in %zu classes), %u meshes, %zu nodes, %zu triangles; LDS mesh %d (%u B), tables %u B, mid tables %u B\n",
                      sc->n_objects, classed, classes.size(), sc->n_meshes, nodes.size() / 2, tris.size() / 3, (int)S.lds_mesh, S.lds_bytes, S.tab_bytes, S.mid_bytes);
     }
+    S.deepen = ctx->deepen ? 1u : 0u;
     ctx->S = S;
     ctx->have_scene = true;
     return RTAMD_OK;

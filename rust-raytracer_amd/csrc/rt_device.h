@@ -28,7 +28,7 @@ static constexpr uint32_t LEAF_BIT = 0x80000000u;
 static constexpr uint32_t MISS = 0xFFFFFFFFu;
 
 struct DevMesh { uint32_t node_base, n_nodes, tri_base, normal_base; };   // n_nodes excludes the sentinel
-struct DevTree { uint32_t node_base, n_nodes, first_object, pad; };
+struct DevTree { uint32_t node_base, n_nodes, first_object, deepen; };   // deepen: walk in passes of growing reach (rt_sched.h)
 struct DevCuboid { float center[3], extent[3], inv_extent[3]; float pad[3]; };
 struct DevTriangle { float a[3], b[3], c[3]; float pad[3]; };
 struct DevOp { uint32_t kind; float v[9]; uint32_t pad[2]; };
@@ -101,6 +101,7 @@ struct DevScene {
     const DevObject* classes;
     uint32_t n_classes, n_trees;
     uint32_t mid_bytes;
+    uint32_t deepen;          // object-tree walks of the scheduler kernels are repeated with a growing t_max limit (rt_sched.h)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -399,7 +400,7 @@ struct MidTab {
     const DevScene* S;
     lds_float4* classes;  // 8 per class
     lds_float4* cuboids;  // 3 per cuboid
-    __attribute__((address_space(3))) const uint32_t* trees;   // node_base, n_nodes, first_object, pad per tree
+    __attribute__((address_space(3))) const uint32_t* trees;   // node_base, n_nodes, first_object, deepen per tree
     __attribute__((address_space(3))) const uint32_t* roots;   // kind, index pairs
     __device__ __forceinline__ ObjHead object(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_object(p[0], p[1], p[2]); }
     __device__ __forceinline__ ObjXf object_xf(uint32_t i) const { const float4* p = (const float4*)(S->objects + i); return unpack_xf(p[3], p[4], p[5]); }
@@ -407,7 +408,7 @@ struct MidTab {
     __device__ __forceinline__ OpRec op(uint32_t i) const { const float4* p = (const float4*)(S->ops + i); return unpack_op(p[0], p[1], p[2]); }
     __device__ __forceinline__ CuboidRec cuboid(uint32_t i) const { return unpack_cuboid(lds_load4(cuboids + 3 * i), lds_load4(cuboids + 3 * i + 1), lds_load4(cuboids + 3 * i + 2)); }
     __device__ __forceinline__ DevRootItem root(uint32_t i) const { return DevRootItem{roots[2 * i], roots[2 * i + 1]}; }
-    __device__ __forceinline__ DevTree tree(uint32_t i) const { return DevTree{trees[4 * i], trees[4 * i + 1], trees[4 * i + 2], 0u}; }
+    __device__ __forceinline__ DevTree tree(uint32_t i) const { return DevTree{trees[4 * i], trees[4 * i + 1], trees[4 * i + 2], trees[4 * i + 3]}; }
     __device__ __forceinline__ InstRec inst(uint32_t i) const { const float4* p = (const float4*)(S->insts + i); return unpack_inst(p[0], p[1]); }
     __device__ __forceinline__ ObjHead cls_head(uint32_t c) const { return unpack_object(lds_load4(classes + 8 * c), lds_load4(classes + 8 * c + 1), lds_load4(classes + 8 * c + 2)); }
     __device__ __forceinline__ ObjXf cls_xf(uint32_t c) const { return unpack_xf(lds_load4(classes + 8 * c + 3), lds_load4(classes + 8 * c + 4), lds_load4(classes + 8 * c + 5)); }

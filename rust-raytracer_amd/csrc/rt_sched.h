@@ -67,6 +67,17 @@ static constexpr uint32_t NODE_STAY_NUM = RTAMD_NODE_STAY_NUM, NODE_STAY_DEN = R
 #ifndef RTAMD_VOTE_W
 #define RTAMD_VOTE_W 16, 16, 1, 1, 1
 #endif
+// Object-tree walks in passes of growing reach (see tree_span): a ray is limited if it would cross more than DEEP_SPAN
+// object spacings; the first pass reaches DEEP_START spacings, each further one DEEP_GROW times as far.
+#ifndef RTAMD_DEEP_START
+#define RTAMD_DEEP_START 1
+#endif
+#ifndef RTAMD_DEEP_SPAN
+#define RTAMD_DEEP_SPAN 2
+#endif
+#ifndef RTAMD_DEEP_GROW
+#define RTAMD_DEEP_GROW 4
+#endif
 #ifndef RTAMD_VOTE_MESH_MIN
 #define RTAMD_VOTE_MESH_MIN 16
 #endif
@@ -224,6 +235,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
     uint32_t root_i = 0;
     uint32_t t_i = 0, t_n = 0, t_base = 0, t_first = 0;
+    float t_lim = __builtin_inff();   // object-tree walk: nothing beyond this ray parameter is visited in the current pass (see tree_span)
     uint32_t o_cur = 0, o_end = 0;
     uint32_t oi = 0;
     f3 opos = mk(0, 0, 0), odir = mk(0, 0, 1), oinv = mk(0, 0, 0);
@@ -250,6 +262,60 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     uint32_t ks = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;                   // nothing is left for this wave to claim
+
+    // Object trees are walked in the reference's fixed order, which is not front to back: a ray that grazes a scene of
+    // thousands of objects visits every object whose box it crosses until the walk happens upon its nearest hit, and a
+    // launch cannot end before its slowest ray.  The walk is therefore repeated with a growing limit on the ray parameter:
+    // a pass visits what the reference's walk would visit had it started with t_max = limit.  Such a pass is exact once it
+    // accepts a hit: box tests are monotone in t_max (`t0 <= t_max + 0.01`), so a pass with a smaller t_max visits a subset
+    // of the reference's nodes and accepts a subset of its hits, and every hit the reference accepts at t <= limit is still
+    // reached, because the boxes above it are entered no later than t plus rounding, which stays below the 0.01 slack
+    // while the ray parameters involved are below 2048 (checked per ray; other rays walk once, unlimited).  From then on
+    // the running t_max of the pass equals the reference's.  A pass that accepts nothing leaves the ray untouched and
+    // the next one starts from the root with four times the reach; past the tree's bounds the limit is dropped.
+    // Scenes whose tables fit LDS hold at most 64 objects: no tree of theirs is worth it; and the upload marks only trees of
+    // mesh objects for it (entering a sphere costs less than a repeated descent from the root).  Compiled out for both.
+    constexpr bool DEEPEN = !Tab::small_scene && MESHLOC != MESH_NONE;
+    // (entry and exit parameter of the ray through the root box of the current object tree)
+    auto tree_span = [&](float& t_en, float& t_ex) -> float {
+        const float4* np = S.nodes + 2 * (size_t)t_base;
+        const float4 n0 = np[0], n1 = np[1];
+        const f3 pa = (mk(n0.x, n0.y, n0.z) - wpos) * winv, pb = (mk(n0.w, n1.x, n1.y) - wpos) * winv;
+        t_en = max2(min2(pa.x, pb.x), max2(min2(pa.y, pb.y), min2(pa.z, pb.z)));
+        t_ex = min2(max2(pa.x, pb.x), min2(max2(pa.y, pb.y), max2(pa.z, pb.z)));
+        // spacing of the objects, taken as spread over the two largest extents of the box (a guess that only steers the
+        // limits: any value gives the same hits)
+        const float ex = n0.w - n0.x, ey = n1.x - n0.y, ez = n1.y - n0.z;
+        const float lo = min2(ex, min2(ey, ez));
+        const float area = lo == ex ? ey * ez : (lo == ey ? ex * ez : ex * ey);
+        return sqrtf(area / (0.5f * (float)t_n));
+    };
+    // Only a ray that would cross many objects is limited (the passes of a short walk cost more than they save): the
+    // first pass reaches 8 object spacings into the tree's box, each further one four times as far.
+    auto walk_begin = [&](const uint32_t tree_deepen) {
+        t_lim = __builtin_inff();
+        if (DEEPEN && S.deepen && tree_deepen) {
+            float t_en, t_ex;
+            const float cell = tree_span(t_en, t_ex);
+            const float s0 = t_en > 0.0f ? t_en : 0.0f;
+            const float start = s0 + (float)RTAMD_DEEP_START * cell;
+            // (every comparison is false on NaN: such rays walk once, unlimited)
+            if (fabsf(t_en) < 2048.0f && fabsf(t_ex) < 2048.0f && t_ex - s0 > (float)RTAMD_DEEP_SPAN * cell && start < wtmax) t_lim = start;
+        }
+    };
+    // The walk has ended.  True: it found nothing within its limit and starts over with a wider one.
+    auto walk_again = [&]() -> bool {
+        if (!DEEPEN || !(t_lim < wtmax)) return false;
+        float t_en, t_ex;
+        (void)tree_span(t_en, t_ex);
+        const float s0 = t_en > 0.0f ? t_en : 0.0f;
+        const float wider = s0 + (t_lim - s0) * (float)RTAMD_DEEP_GROW;
+        t_lim = wider < t_ex + 0.02f ? wider : __builtin_inff();
+        t_i = 0;
+        return true;
+    };
+    // t_max of the object-tree walk and of the objects entered from it
+    auto walk_tmax = [&]() -> float { return (DEEPEN && t_lim < wtmax) ? t_lim : wtmax; };
 
     // One node of the current mesh tree (bvh.rs:227-252): visit test, then into the leaf, on to the next
     // node, or along the skip link.  Used by the NODE phase and, for a mesh's root, by the OBJ phase.
@@ -457,11 +523,12 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
                 const bool leaf = (A & LEAF_BIT) != 0u;
                 const uint32_t first = A & ~LEAF_BIT;
-                const bool pass = node_passes(n0, n1, wpos, winv, signbit32(winv.x), signbit32(winv.y), signbit32(winv.z), wtmax);
+                const bool pass = node_passes(n0, n1, wpos, winv, signbit32(winv.x), signbit32(winv.y), signbit32(winv.z), walk_tmax());
                 const bool enter = pass && leaf && first < B;
                 o_cur = enter ? t_first + first : o_cur; o_end = enter ? t_first + B : o_end;
                 t_i = enter ? t_i : ((pass || leaf) ? t_i + 1 : A);
-                const bool tree_done = !enter && t_i >= t_n;
+                bool tree_done = !enter && t_i >= t_n;
+                if (tree_done && walk_again()) tree_done = false;
                 fl &= tree_done ? ~F_INTREE : ~0u;
                 st = (enter || tree_done) ? ST_OBJ : ST_TNODE;
             }
@@ -484,7 +551,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 if (o_cur == o_end) {
                     if (fl & F_INTREE) {  // leaf of the object tree finished: i += 1
                         t_i++;
-                        if (t_i >= t_n) fl &= ~F_INTREE; else st = ST_TNODE;
+                        if (t_i >= t_n && !walk_again()) fl &= ~F_INTREE; else st = ST_TNODE;
                     }
                     if (!(fl & F_INTREE) && st == ST_OBJ) {
                         if (root_i >= S.n_root) {
@@ -496,7 +563,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                                 const DevTree tr = tab.tree(it.index);
                                 t_base = tr.node_base; t_n = tr.n_nodes; t_first = tr.first_object; t_i = 0;
                                 if (!S.any_box) winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // bvh.rs:220
-                                if (t_n > 0) { fl |= F_INTREE; st = ST_TNODE; }
+                                if (t_n > 0) { fl |= F_INTREE; st = ST_TNODE; walk_begin(tr.deepen); }
                             }
                         }
                     }
@@ -510,6 +577,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     // the wrappers nor a reciprocal direction per object.  It only ever skips what the object's own first
                     // test would turn away (the comparisons are false for NaN, so nothing is skipped on one).
                     // Large scenes read the object's 32-byte instance record and take the rest from its class in LDS.
+                    const float tm_in = (fl & F_INTREE) ? walk_tmax() : wtmax;   // t_max the object is entered with
                     ObjHead ob;
                     InstRec in = tab.inst(oi);
                     const bool classed = Tab::has_inst && in.cls != CLS_NONE;
@@ -526,13 +594,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         const float bt0 = max2(min2(pa.x, pb.x), max2(min2(pa.y, pb.y), min2(pa.z, pb.z)));
                         const float bt1 = min2(max2(pa.x, pb.x), min2(max2(pa.y, pb.y), max2(pa.z, pb.z)));
                         const float err = 1e-6f * fmaxf(fabsf(bt0), fabsf(bt1)) + ox.slack;   // NaN or inf roots: nothing is skipped
-                        skip = (bt0 > bt1 + err) || (bt0 > wtmax * 1.00001f + err) || (bt1 < -err);
+                        skip = (bt0 > bt1 + err) || (bt0 > tm_in * 1.00001f + err) || (bt1 < -err);
                     }
                     if (!skip) {
                     ObjXf xf;   // read with the head: one round trip instead of two
                     if (classed) { xf = tab.cls_xf(in.cls); xf.off = in.off; }
                     else xf = tab.object_xf(oi);
-                    opos = wpos; otmax = wtmax;
+                    opos = wpos; otmax = tm_in;
                     odir = wdir;
                     oscale = ob.scale;
                     if (ob.xf_kind & XF_GENERIC) {
