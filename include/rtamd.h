@@ -313,8 +313,12 @@ enum rtamd_option {
     RTAMD_OPT_MIN_BATCH = 8,    /* rays per wave below which a short ray queue is not spread over more waves (1..64, default 4) */
     RTAMD_OPT_STATIC_SHARE = 7, /* eighths (0..8, default 6) of a ray queue dealt to the waves up front; the rest is claimed dynamically */
     RTAMD_OPT_DEPTH_FIRST_ROUNDS = 9, /* scatter_rays != 1: 1 (default) rounds of one trace launch over every pixel's next ray, 0 one lane per pixel */
-    RTAMD_OPT_TREE_DEEPENING = 10 /* 1 (default): object trees of >= 256 nodes are walked in passes of growing reach (same hits as one walk,
-                                     see rt_sched.h); 0: one walk in the reference's order */
+    RTAMD_OPT_TREE_DEEPENING = 10 /* object trees of mesh objects (>= 256 nodes) walked in passes of growing reach instead of once in the
+                                     reference's order, which is not front to back: 0 never; 1 (default) in rtamd_render*; 2 also in the
+                                     batch entry points.  Same hits, with one exception: the reference reports a spurious hit at t = 0
+                                     for a triangle its ray is parallel to within ~1e-7 rad (triangle.rs:26-28), wherever along the ray
+                                     that triangle lies; a walk in passes reports the ray's real nearest hit when it finds one before
+                                     its reach includes that triangle (measured: 2 of 16 million grazing rays) */
 };
 int rtamd_set_option(rtamd_context* ctx, int option, int64_t value);
 /* Average duration (ms) and launch count of the closest-hit / any-hit trace kernels since the last

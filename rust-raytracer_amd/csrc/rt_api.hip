@@ -25,7 +25,7 @@ struct rtamd_context {
     std::string error;
     LaunchCfg cfg;
     bool profile = false;
-    bool deepen = true;      // object-tree walks with a growing t_max limit (exact; see rt_sched.h)
+    int deepen = 1;          // object-tree walks in passes of growing reach (rt_sched.h): 0 never, 1 in the render entry points, 2 also in the batch entry points
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
@@ -399,7 +399,10 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
             return RTAMD_OK;
         case RTAMD_OPT_LDS_SCENE: ctx->cfg.use_lds = value != 0; return RTAMD_OK;
         case RTAMD_OPT_DEPTH_FIRST_ROUNDS: ctx->df_rounds = value != 0; return RTAMD_OK;
-        case RTAMD_OPT_TREE_DEEPENING: ctx->deepen = value != 0; ctx->S.deepen = ctx->deepen ? 1u : 0u; return RTAMD_OK;
+        case RTAMD_OPT_TREE_DEEPENING:
+            if (value < 0 || value > 2) return fail(ctx, RTAMD_E_INVALID, "tree deepening mode must be 0, 1 or 2");
+            ctx->deepen = (int)value; ctx->S.deepen = ctx->deepen >= 1 ? 1u : 0u;
+            return RTAMD_OK;
         case RTAMD_OPT_SCHEDULER: ctx->cfg.scheduler = value != 0; return RTAMD_OK;
         case RTAMD_OPT_CHUNK:
             if (value < 64 || value > 4096 || (value & (value - 1))) return fail(ctx, RTAMD_E_INVALID, "chunk must be a power of two in [64, 4096]");
@@ -741,11 +744,23 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         std::fprintf(stderr, "rtamd: %u objects (%zu in %zu classes), %u meshes, %zu nodes, %zu triangles; LDS mesh %d (%u B), tables %u B, mid tables %u B\n",
                      sc->n_objects, classed, classes.size(), sc->n_meshes, nodes.size() / 2, tris.size() / 3, (int)S.lds_mesh, S.lds_bytes, S.tab_bytes, S.mid_bytes);
     }
-    S.deepen = ctx->deepen ? 1u : 0u;
+    S.deepen = ctx->deepen >= 1 ? 1u : 0u;   // what the render entry points pass to their kernels; the batch entry points decide per call
     ctx->S = S;
     ctx->have_scene = true;
     return RTAMD_OK;
 }
+
+namespace {
+// The scene as the batch entry points hand it to their kernels.  They are the parity entry points: every ray gets the
+// reference's answer, the spurious t = 0 hits of near-parallel triangles (triangle.rs:26-28) included, wherever along the
+// ray such a triangle lies -- which only a walk over everything the ray crosses can find.  The walk in passes of growing
+// reach is therefore opt-in here (RTAMD_OPT_TREE_DEEPENING = 2).
+DevScene batch_scene(const rtamd_context* ctx) {
+    DevScene S = ctx->S;
+    S.deepen = ctx->deepen >= 2 ? 1u : 0u;
+    return S;
+}
+}  // namespace
 
 int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream) {
     if (!ctx || !rays || !out) return RTAMD_E_INVALID;
@@ -758,7 +773,7 @@ int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_
     uint32_t* head = ctx->work_head + (ctx->head_next++ % HEAD_RING);
     // kernel timing only on the context's own stream, where the events are collected right after the call
     if (!stream) timed_begin(ctx, 0, st);
-    HIP_TRY(ctx, launch_trace_closest(ctx->S, ctx->cfg, rb, hb, n, head, st));
+    HIP_TRY(ctx, launch_trace_closest(batch_scene(ctx), ctx->cfg, rb, hb, n, head, st));
     if (!stream) timed_end(ctx, st);
     if (!stream) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -776,7 +791,7 @@ int rtamd_trace_any_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n,
     RayBatch rb{rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tmax};
     uint32_t* head = ctx->work_head + (ctx->head_next++ % HEAD_RING);
     if (!stream) timed_begin(ctx, 1, st);
-    HIP_TRY(ctx, launch_trace_any(ctx->S, ctx->cfg, rb, out, n, head, st));
+    HIP_TRY(ctx, launch_trace_any(batch_scene(ctx), ctx->cfg, rb, out, n, head, st));
     if (!stream) timed_end(ctx, st);
     if (!stream) {
         HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -807,7 +822,7 @@ int rtamd_trace_closest_static(rtamd_context* ctx, const rtamd_rays* rays, size_
     HitBatch hb{out->obj, out->prim, out->t, out->u, out->v};
     LaunchCfg cfg = ctx->cfg;
     cfg.scheduler = 1;   // the kernel that uses the scratch word
-    HIP_TRY(ctx, launch_trace_closest(ctx->S, cfg, rb, hb, n, head, st));   // zeroes its head word on `st` first
+    HIP_TRY(ctx, launch_trace_closest(batch_scene(ctx), cfg, rb, hb, n, head, st));   // zeroes its head word on `st` first
     if (!stream) HIP_TRY(ctx, hipStreamSynchronize(st));
     return RTAMD_OK;
 }

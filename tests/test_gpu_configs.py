@@ -51,6 +51,65 @@ def test_grid_230x230_scheduler_equals_plain_kernel(rt, grid_pair):
     assert np.array_equal(occ_a, occ_b)
 
 
+def grazing_rays(n, seed, half_extent, z_range, dz):
+    """Rays that start inside the grid's slab and run nearly parallel to it: they cross hundreds of instance boxes."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((7, n), np.float32)
+    rays[0] = rng.uniform(-half_extent, half_extent, n)
+    rays[1] = rng.uniform(-half_extent, half_extent, n)
+    rays[2] = rng.uniform(z_range[0], z_range[1], n)
+    a = rng.uniform(0.0, 2.0 * np.pi, n)
+    a[: n // 4] = np.round(a[: n // 4] / (np.pi / 4)) * (np.pi / 4)      # a quarter exactly along the axes and diagonals
+    d = np.stack([np.cos(a), np.sin(a), rng.uniform(-dz, dz, n)])
+    d[:, : n // 8][np.abs(d[:, : n // 8]) < 1e-6] = 0.0                   # with components that are exactly zero
+    rays[3:6] = (d / np.linalg.norm(d, axis=0)).astype(np.float32)
+    rays[6] = 1e12
+    return rays
+
+
+def test_grid_230x230_grazing_rays_and_the_walk_in_passes(rt, grid_pair):
+    """Grazing rays (they cross hundreds of instance boxes), rays aimed from far outside, closest and any-hit, against the
+    oracle, bit for bit.  Then the object-tree walk in passes of growing reach (what the render entry points use; opt-in
+    for the batch entry points) against the single walk: identical on these rays.  It may differ only where the reference
+    reports a spurious t = 0 hit of a near-parallel triangle (triangle.rs:26-28) that lies beyond the ray's real nearest
+    hit -- about one grazing ray in ten million (tools/deepening_stress.py counts them)."""
+    gpu, cpu, cam = grid_pair
+    graze = grazing_rays(6000, 71, 430.0, (-1.0, 4.0), 0.03)
+    far = random_rays(4000, seed=72, center=(0, 0, 2), radius=420.0)
+    far[0:3] = far[0:3] * 40.0                                            # origins up to 17 000 away: parameters beyond the limit's range
+    mixed = random_rays(6000, seed=73, center=(0, 0, 2), radius=430.0)
+    # aimed at the grid from 1000 to 3000 away, low over the horizon: ray parameters on both sides of the limit's range
+    rng = np.random.default_rng(75)
+    n = 4000
+    aimed = np.zeros((7, n), np.float32)
+    ang = rng.uniform(0.0, 2.0 * np.pi, n)
+    dist = rng.uniform(1000.0, 3000.0, n)
+    aimed[0], aimed[1], aimed[2] = dist * np.cos(ang), dist * np.sin(ang), rng.uniform(1.0, 60.0, n)
+    target = np.stack([rng.uniform(-400.0, 400.0, n), rng.uniform(-400.0, 400.0, n), rng.uniform(0.0, 3.0, n)])
+    d = target - aimed[0:3].astype(np.float64)
+    aimed[3:6] = (d / np.linalg.norm(d, axis=0)).astype(np.float32)
+    aimed[6] = 1e12
+    rays = np.ascontiguousarray(np.concatenate([graze, far, mixed, aimed], axis=1))
+    a = gpu.trace_closest(rays)
+    ref = cpu.trace_closest(rays)
+    hits = check_closest(rt, a, ref)
+    assert hits > 4000
+    assert not np.any((ref["obj"] >= 0) & (ref["t"] == 0.0))              # none of these rays is one of the spurious hits
+    any_rays = rays.copy()
+    any_rays[6] = np.random.default_rng(74).choice(np.array([3.0, 40.0, 700.0, 1e12], np.float32), rays.shape[1])
+    occ = gpu.trace_any(any_rays)
+    assert np.array_equal(occ, cpu.trace_any(any_rays)[0])
+    try:
+        gpu.set_option(rt.OPT_TREE_DEEPENING, 2)
+        b = gpu.trace_closest(rays)
+        occ_b = gpu.trace_any(any_rays)
+    finally:
+        gpu.set_option(rt.OPT_TREE_DEEPENING, 1)
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert np.array_equal(occ, occ_b)
+
+
 def test_grid_8k_sub_rectangle_render_in_chunks(rt, grid_pair):
     """A sub-rectangle of the 7680x4320 frame against the oracle, max_paths forcing several wavefront chunks."""
     gpu, cpu, cam = grid_pair

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Object-tree walks in passes of growing reach against the single walk, on millions of rays (GPU against GPU, bit for bit).
+Counts the rays that differ and checks that each is the one licensed case: a spurious t = 0 hit of the single walk.
+
+    python tools/deepening_stress.py [--rays 2000000] [--rounds 4]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as entry  # noqa: E402
+from test_gpu_configs import grazing_rays  # noqa: E402
+from test_gpu_trace import random_rays  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=2_000_000)
+    ap.add_argument("--rounds", type=int, default=4)
+    args = ap.parse_args()
+    rt = entry.load_package()
+    sky = rt.load_skybox(max_width=512)
+    scenes = [("grid 230x230", rt.Scene.grid(230, 230, sky=sky, cam=(640, 480)), 430.0, (-1.0, 4.0)),
+              ("flattened grid 40x40", rt.Scene.grid(40, 40, sky=sky, cam=(640, 480), flat=1), 75.0, (-1.0, 4.0)),
+              ("scatter", rt.Scene.scatter(3000, seed=5, sky=sky, cam=(640, 480)), 60.0, (-2.0, 8.0))]
+    bad = 0
+    for name, scene, half, zr in scenes:
+        scene.upload(0)
+        for r in range(args.rounds):
+            n = args.rays
+            parts = [grazing_rays(n // 2, 100 + r, half, zr, (0.002, 0.03, 0.2, 1.0)[r % 4]),
+                     random_rays(n // 4, seed=200 + r, center=(0, 0, 2), radius=half),
+                     random_rays(n // 4, seed=300 + r, center=(0, 0, 2), radius=half * (3.0, 6.0, 12.0, 40.0)[r % 4])]
+            rays = np.ascontiguousarray(np.concatenate(parts, axis=1))
+            any_rays = rays.copy()
+            any_rays[6] = np.random.default_rng(400 + r).choice(np.array([1.0, 25.0, 300.0, 1e12], np.float32), rays.shape[1])
+            scene.set_option(rt.OPT_TREE_DEEPENING, 2)      # the batch entry points walk in passes only when asked to
+            a, occ_a = scene.trace_closest(rays), scene.trace_any(any_rays)
+            scene.set_option(rt.OPT_TREE_DEEPENING, 1)
+            b, occ_b = scene.trace_closest(rays), scene.trace_any(any_rays)
+            differ = np.zeros(rays.shape[1], bool)
+            for k in a:
+                differ |= a[k].view(np.uint32) != b[k].view(np.uint32)
+            # the only licensed difference: the single walk (= the reference) reports a spurious hit at t = 0 (triangle.rs:26-28)
+            spurious = (b["obj"] != rt.MISS) & (b["t"] == 0.0) & (b["u"] == 0.0) & (b["v"] == 0.0)
+            unexplained = int((differ & ~spurious).sum())
+            # any-hit: a spurious hit occludes at any t_max; the walk in passes may miss it and report the ray free
+            occ_differ = occ_a != occ_b
+            occ_unexplained = int((occ_differ & ~((occ_b == 1) & (occ_a == 0))).sum())
+            bad += unexplained + occ_unexplained
+            print(f"{name}: round {r}: {rays.shape[1]} closest + any rays, {int((a['obj'] != rt.MISS).sum())} hits, {int(occ_a.sum())} occluded; "
+                  f"closest rays that differ {int(differ.sum())} (all spurious t = 0 hits of the single walk: {unexplained == 0}), "
+                  f"any-hit rays that differ {int(occ_differ.sum())} (single walk occluded, passes free: {occ_unexplained == 0})", flush=True)
+    print("OK" if bad == 0 else f"UNEXPLAINED DIFFERENCES: {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
