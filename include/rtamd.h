@@ -311,7 +311,8 @@ enum rtamd_option {
     RTAMD_OPT_BLOCKS_PER_CU = 5,/* persistent 512-thread blocks per CU (1..8, default 2) */
     RTAMD_OPT_STREAMS = 6,      /* render: pixel groups in flight at once, each on its own HIP stream (1..8, default 1) */
     RTAMD_OPT_MIN_BATCH = 8,    /* rays per wave below which a short ray queue is not spread over more waves (1..64, default 4) */
-    RTAMD_OPT_STATIC_SHARE = 7, /* eighths (0..8, default 6) of a ray queue dealt to the waves up front; the rest is claimed dynamically */
+    RTAMD_OPT_STATIC_SHARE = 7, /* eighths (0..8) of a ray queue dealt to the waves up front; the rest is claimed dynamically.  Unless set,
+                                   rtamd_upload_scene picks 6, or 3 for a scene with an object tree of >= 256 nodes */
     RTAMD_OPT_DEPTH_FIRST_ROUNDS = 9, /* scatter_rays != 1: 1 (default) rounds of one trace launch over every pixel's next ray, 0 one lane per pixel */
     RTAMD_OPT_TREE_DEEPENING = 10 /* object trees of mesh objects (>= 256 nodes) walked in passes of growing reach instead of once in the
                                      reference's order, which is not front to back: 0 never; 1 (default) in rtamd_render*; 2 also in the
