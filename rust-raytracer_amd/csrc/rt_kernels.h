@@ -12,9 +12,12 @@ static constexpr int STAGE_BLOCK = 1024; // threads per block of the queue-build
 #define RTAMD_SCHED_WAVES 4
 #endif
 #ifndef RTAMD_NOMESH_WAVES
-#define RTAMD_NOMESH_WAVES 6
+#define RTAMD_NOMESH_WAVES 4
 #endif
-static constexpr int NOMESH_WAVES_PER_SIMD = RTAMD_NOMESH_WAVES;  // scheduler kernels of scenes without meshes: three 8-wave blocks per CU, 80 VGPRs
+// scheduler kernels of scenes without meshes (mesh phases compiled out).  At 6 (three 8-wave blocks per CU, 80 VGPRs) the kernel
+// spills 14 registers and the scratch traffic costs more than the occupancy returns: 10 000 spheres 1 177 / 2 841 Mrays/s at
+// 1080x960 / 4K against 1 303 / 2 962 at 4 (and 1 174 / 2 446 at 5, which still fits only two blocks)
+static constexpr int NOMESH_WAVES_PER_SIMD = RTAMD_NOMESH_WAVES;
 static constexpr int SCHED_WAVES_PER_SIMD = RTAMD_SCHED_WAVES;  // register budget of the scheduler kernels: two 8-wave blocks per CU = 4 waves/SIMD, 128 VGPRs
 
 struct RayBatch { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; };

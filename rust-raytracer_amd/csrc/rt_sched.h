@@ -35,8 +35,7 @@ struct LdsMesh {
     lds_float4* tris;
 };
 // Where the mesh trees of a launch live: decided on the host per scene.
-// MESH_NONE: the scene has no mesh at all (spheres, cuboids, triangles only): the mesh phases are compiled out, which
-// frees enough registers for a higher occupancy (see NOMESH_WAVES_PER_SIMD).
+// MESH_NONE: the scene has no mesh at all (spheres, cuboids, triangles only): the mesh phases are compiled out.
 enum : int { MESH_GLOBAL = 0, MESH_LDS = 1, MESH_MIXED = 2, MESH_NONE = 3 };
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
