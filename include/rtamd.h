@@ -314,7 +314,7 @@ enum rtamd_option {
     RTAMD_OPT_STATIC_SHARE = 7, /* eighths (0..8) of a ray queue dealt to the waves up front; the rest is claimed dynamically.  Unless set,
                                    rtamd_upload_scene picks 6, or 3 for a scene with an object tree of >= 256 nodes */
     RTAMD_OPT_DEPTH_FIRST_ROUNDS = 9, /* scatter_rays != 1: 1 (default) rounds of one trace launch over every pixel's next ray, 0 one lane per pixel */
-    RTAMD_OPT_TREE_DEEPENING = 10 /* object trees of mesh objects (>= 256 nodes) walked in passes of growing reach instead of once in the
+    RTAMD_OPT_TREE_DEEPENING = 10 /* object trees of >= 256 nodes walked in passes of growing reach instead of once in the
                                      reference's order, which is not front to back: 0 never; 1 (default) in rtamd_render*; 2 also in the
                                      batch entry points.  Same hits, with one exception: the reference reports a spurious hit at t = 0
                                      for a triangle its ray is parallel to within ~1e-7 rad (triangle.rs:26-28), wherever along the ray

@@ -503,11 +503,11 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         dt.node_base = (uint32_t)(nodes.size() / 2);
         dt.n_nodes = tr.n_nodes ? tr.n_nodes - 1 : 0;
         dt.first_object = tr.first_object;
-        // walks in passes of growing reach pay where entering an object is expensive (a mesh walk), not for trees of
-        // spheres or cuboids, whose objects cost less than a repeated descent from the root
+        // walks in passes of growing reach (rt_sched.h): 1 a tree of mesh objects, 2 a tree of cheap objects (limits only its
+        // long rays), 0 a small tree
         uint32_t n_mesh = 0;
         for (uint32_t k = 0; k < tr.n_objects; k++) n_mesh += sc->objects[tr.first_object + k].geom_kind == RTAMD_GEOM_MESH ? 1u : 0u;
-        dt.deepen = (tr.n_nodes >= 257u && 2u * (uint64_t)n_mesh >= tr.n_objects) ? 1u : 0u;
+        dt.deepen = tr.n_nodes >= 257u ? (2u * (uint64_t)n_mesh >= tr.n_objects ? 1u : 2u) : 0u;
         if ((rc = convert_tree(ctx, tr.nodes, tr.n_nodes, tr.n_objects, "object tree", nodes))) return rc;
         trees.push_back(dt);
     }

@@ -67,12 +67,19 @@ static constexpr uint32_t NODE_STAY_NUM = RTAMD_NODE_STAY_NUM, NODE_STAY_DEN = R
 #define RTAMD_VOTE_W 16, 16, 1, 1, 1
 #endif
 // Object-tree walks in passes of growing reach (see tree_span): a ray is limited if it would cross more than DEEP_SPAN
-// object spacings; the first pass reaches DEEP_START spacings, each further one DEEP_GROW times as far.
+// object spacings; the first pass reaches DEEP_START spacings, each further one DEEP_GROW times as far (*_CHEAP: trees
+// whose objects are not meshes).
 #ifndef RTAMD_DEEP_START
 #define RTAMD_DEEP_START 1
 #endif
 #ifndef RTAMD_DEEP_SPAN
 #define RTAMD_DEEP_SPAN 2
+#endif
+#ifndef RTAMD_DEEP_START_CHEAP
+#define RTAMD_DEEP_START_CHEAP 12
+#endif
+#ifndef RTAMD_DEEP_SPAN_CHEAP
+#define RTAMD_DEEP_SPAN_CHEAP 32
 #endif
 #ifndef RTAMD_DEEP_GROW
 #define RTAMD_DEEP_GROW 4
@@ -272,9 +279,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     // while the ray parameters involved are below 2048 (checked per ray; other rays walk once, unlimited).  From then on
     // the running t_max of the pass equals the reference's.  A pass that accepts nothing leaves the ray untouched and
     // the next one starts from the root with four times the reach; past the tree's bounds the limit is dropped.
-    // Scenes whose tables fit LDS hold at most 64 objects: no tree of theirs is worth it; and the upload marks only trees of
-    // mesh objects for it (entering a sphere costs less than a repeated descent from the root).  Compiled out for both.
-    constexpr bool DEEPEN = !Tab::small_scene && MESHLOC != MESH_NONE;
+    // Scenes whose tables fit LDS hold at most 64 objects: no tree of theirs is worth it, and the code is compiled out.
+    constexpr bool DEEPEN = !Tab::small_scene;
     // (entry and exit parameter of the ray through the root box of the current object tree)
     auto tree_span = [&](float& t_en, float& t_ex) -> float {
         const float4* np = S.nodes + 2 * (size_t)t_base;
@@ -297,9 +303,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             float t_en, t_ex;
             const float cell = tree_span(t_en, t_ex);
             const float s0 = t_en > 0.0f ? t_en : 0.0f;
-            const float start = s0 + (float)RTAMD_DEEP_START * cell;
+            // Trees of mesh objects (tree_deepen = 1): every object a pass leaves out is a whole mesh walk.  Trees of cheap
+            // objects (spheres, cuboids; 2): an object costs less than a second descent from the root, only the long rays
+            // are limited, and later.
+            const float start = s0 + (tree_deepen == 1u ? (float)RTAMD_DEEP_START : (float)RTAMD_DEEP_START_CHEAP) * cell;
+            const float span = (tree_deepen == 1u ? (float)RTAMD_DEEP_SPAN : (float)RTAMD_DEEP_SPAN_CHEAP) * cell;
             // (every comparison is false on NaN: such rays walk once, unlimited)
-            if (fabsf(t_en) < 2048.0f && fabsf(t_ex) < 2048.0f && t_ex - s0 > (float)RTAMD_DEEP_SPAN * cell && start < wtmax) t_lim = start;
+            if (fabsf(t_en) < 2048.0f && fabsf(t_ex) < 2048.0f && t_ex - s0 > span && start < wtmax) t_lim = start;
         }
     };
     // The walk has ended.  True: it found nothing within its limit and starts over with a wider one.

@@ -27,7 +27,8 @@ def main():
     sky = rt.load_skybox(max_width=512)
     scenes = [("grid 230x230", rt.Scene.grid(230, 230, sky=sky, cam=(640, 480)), 430.0, (-1.0, 4.0)),
               ("flattened grid 40x40", rt.Scene.grid(40, 40, sky=sky, cam=(640, 480), flat=1), 75.0, (-1.0, 4.0)),
-              ("scatter", rt.Scene.scatter(3000, seed=5, sky=sky, cam=(640, 480)), 60.0, (-2.0, 8.0))]
+              ("scatter", rt.Scene.scatter(3000, seed=5, sky=sky, cam=(640, 480)), 60.0, (-2.0, 8.0)),
+              ("10 000 spheres", rt.Scene.spheres(n=10000, seed=1, sky=sky, cam=(640, 480)), 40.0, (0.0, 6.0))]
     bad = 0
     for name, scene, half, zr in scenes:
         scene.upload(0)
