@@ -1318,6 +1318,14 @@ int rtamd_timeline_read(rtamd_context* ctx, unsigned long long out[8], int reset
     HIP_TRY(ctx, rtamd::timeline_read(out, reset));
     return RTAMD_OK;
 }
+// The per-launch table: 16 launch slots x 8192 waves x {start, dry, end, trips}, `words` = capacity of `out`.
+int rtamd_timeline_dump(rtamd_context* ctx, unsigned long long* out, size_t words, int reset) {
+    if (!ctx || !out) return RTAMD_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, rtamd::timeline_dump(out, words, reset));
+    return RTAMD_OK;
+}
 #endif
 #ifdef RTAMD_DIAG
 // Diagnostic build only: per-phase totals of the scheduler kernels (cycles, steps, active lanes) x 5 phases.

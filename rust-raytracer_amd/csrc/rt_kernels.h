@@ -7,7 +7,10 @@ struct rtamd_bvh_node;
 namespace rtamd {
 
 static constexpr int TRACE_BLOCK = 512;  // threads per block of the traversal kernels (8 waves)
-static constexpr int STAGE_BLOCK = 1024; // threads per block of the queue-building stages (one queue atomic per block)
+#ifndef RTAMD_STAGE_BLOCK
+#define RTAMD_STAGE_BLOCK 1024
+#endif
+static constexpr int STAGE_BLOCK = RTAMD_STAGE_BLOCK; // threads per block of the queue-building stages (one queue atomic per block)
 #ifndef RTAMD_SCHED_WAVES
 #define RTAMD_SCHED_WAVES 4
 #endif
@@ -162,6 +165,7 @@ hipError_t build_bvh_device(const float* boxes, uint32_t n, float hit_cost, ::rt
                             hipStream_t st);
 #ifdef RTAMD_TIMELINE
 hipError_t timeline_read(unsigned long long* out, int reset);
+hipError_t timeline_dump(unsigned long long* out, size_t words, int reset);
 #endif
 #ifdef RTAMD_DIAG
 hipError_t diag_read(unsigned long long* out, int reset);

@@ -6,6 +6,8 @@
 // grid that covers the chip and walks its queue with a grid stride; the queue length is read from
 // device memory, so the host never synchronises inside a frame.
 #include "rt_kernels.h"
+#include <algorithm>
+#include <vector>
 #include "rt_sched.h"
 
 namespace rtamd {
@@ -1448,14 +1450,40 @@ hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t
 }
 
 #ifdef RTAMD_TIMELINE
+// out: [0] earliest wave start, [1] latest start, [2] earliest moment a wave found the queue empty, [3] latest wave end (all of
+// the last launch), [4] sum of wave lifetimes, [5] waves, [6] sum of lifetimes after the wave's queue ran dry, [7] loop trips
+// (sums over the launches since the last reset).
 hipError_t timeline_read(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), 64);
+    static std::vector<unsigned long long> tab(TL_MAX_WAVES * 8);
+    hipError_t e = hipMemcpyFromSymbol(tab.data(), HIP_SYMBOL(g_timeline), tab.size() * 8);
     if (e != hipSuccess) return e;
+    unsigned long long r[8] = {~0ull, 0, ~0ull, 0, 0, 0, 0, 0};
+    for (uint32_t w = 0; w < TL_MAX_WAVES; w++) {
+        const unsigned long long* t = tab.data() + 8 * (size_t)w;
+        if (t[5] == 0) continue;
+        if (t[0] < r[0]) r[0] = t[0];
+        if (t[0] > r[1]) r[1] = t[0];
+        if (t[1] && t[1] < r[2]) r[2] = t[1];
+        if (t[2] > r[3]) r[3] = t[2];
+        r[4] += t[3]; r[5] += t[5]; r[6] += t[4]; r[7] += t[6];
+    }
+    for (int k = 0; k < 8; k++) out[k] = r[k];
     if (reset) {
-        unsigned long long z[8] = {~0ull, 0, ~0ull, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), z, 64);
+        std::fill(tab.begin(), tab.end(), 0ull);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), tab.data(), tab.size() * 8);
     }
     return e;
+}
+#endif
+#ifdef RTAMD_TIMELINE
+// The per-launch stamp table (TL_LAUNCH_SLOTS x TL_MAX_WAVES x {start, dry, end, trips}); zeroed when reset.
+hipError_t timeline_dump(unsigned long long* out, size_t words, int reset) {
+    const size_t all = (size_t)TL_LAUNCH_SLOTS * TL_MAX_WAVES * 4;
+    if (words < all) return hipErrorInvalidValue;
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline_launch), all * 8);
+    if (e != hipSuccess || !reset) return e;
+    std::vector<unsigned long long> z(all, 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_launch), z.data(), all * 8);
 }
 #endif
 #ifdef RTAMD_DIAG

@@ -116,17 +116,24 @@ __device__ unsigned long long g_diag[32];
 #endif
 
 // Timeline build only (-DRTAMD_TIMELINE): when the scheduler's waves start, run dry and end, without the per-phase probes
-// of the diagnostic build (which distort the schedule).  [0] earliest wave start, [1] latest start, [2] earliest moment a
-// wave found the queue empty, [3] latest wave end, [4] sum of wave lifetimes, [5] waves, [6] sum of lifetimes after the
-// wave's queue ran dry, [7] loop trips.
+// of the diagnostic build (which distort the schedule).  Every wave of the grid has eight words of its own, written with
+// plain stores when the wave ends (atomics on shared words would queue up behind the scheduler's own queue-head atomic and
+// stretch the very tail they measure): start, moment the queue was found empty (0: never), end of the last launch; summed
+// over the launches since the last reset: lifetime, lifetime after the queue ran dry, launches, loop trips.  Stamps are the
+// device-wide 100 MHz counter.  The host reduces the table (timeline_read).
 #ifdef RTAMD_TIMELINE
-__device__ unsigned long long g_timeline[8];
-#define TL_DECL unsigned long long tl_start = __builtin_amdgcn_s_memtime(), tl_dry = 0, tl_trips = 0;
+static constexpr uint32_t TL_MAX_WAVES = 8192;
+__device__ unsigned long long g_timeline[TL_MAX_WAVES * 8];
+// the same stamps (start, dry, end, trips) kept per launch: the launch is told apart by its queue-head word (consecutive
+// words for the launches of one sample pass), 16 slots
+static constexpr uint32_t TL_LAUNCH_SLOTS = 16;
+__device__ unsigned long long g_timeline_launch[TL_LAUNCH_SLOTS * TL_MAX_WAVES * 4];
+#define TL_DECL unsigned long long tl_start = __builtin_amdgcn_s_memrealtime(), tl_dry = 0, tl_trips = 0;
 #define TL_TRIP tl_trips++;
-#define TL_DRY if (tl_dry == 0) tl_dry = __builtin_amdgcn_s_memtime();
-#define TL_FLUSH if (lane == 0) { const unsigned long long tl_end = __builtin_amdgcn_s_memtime(); atomicMin(&g_timeline[0], tl_start); atomicMax(&g_timeline[1], tl_start); \
-        if (tl_dry) { atomicMin(&g_timeline[2], tl_dry); atomicAdd(&g_timeline[6], tl_end - tl_dry); } atomicMax(&g_timeline[3], tl_end); atomicAdd(&g_timeline[4], tl_end - tl_start); \
-        atomicAdd(&g_timeline[5], 1ull); atomicAdd(&g_timeline[7], tl_trips); }
+#define TL_DRY if (tl_dry == 0) tl_dry = __builtin_amdgcn_s_memrealtime();
+#define TL_FLUSH if (lane == 0 && wave_id < TL_MAX_WAVES) { const unsigned long long tl_end = __builtin_amdgcn_s_memrealtime(); unsigned long long* w = g_timeline + 8 * (size_t)wave_id; \
+        w[0] = tl_start; w[1] = tl_dry; w[2] = tl_end; w[3] += tl_end - tl_start; w[4] += tl_dry ? tl_end - tl_dry : 0ull; w[5] += 1ull; w[6] += tl_trips; \
+        unsigned long long* q = g_timeline_launch + 4 * ((size_t)(((uintptr_t)work_head >> 2) % TL_LAUNCH_SLOTS) * TL_MAX_WAVES + wave_id); q[0] = tl_start; q[1] = tl_dry; q[2] = tl_end; q[3] = tl_trips; }
 #else
 #define TL_DECL
 #define TL_TRIP

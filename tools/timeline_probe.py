@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="bunny", choices=["bunny", "grid", "spheres"])
     ap.add_argument("--kind", default="closest", choices=["closest", "any"])
+    ap.add_argument("--coherent", action="store_true", help="rays in image order instead of a random permutation")
     args = ap.parse_args()
     rt = entry.load_package()
     W, H = 2160, 1920
@@ -41,7 +42,9 @@ def main():
     v = (2.0 * (ys / H) - 1.0).reshape(-1, 1)
     d = d0[None, :] + u * hor[None, :] + v * ver[None, :]
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    d = d[np.random.default_rng(1).permutation(len(d))].astype(np.float32)
+    if not args.coherent:
+        d = d[np.random.default_rng(1).permutation(len(d))]
+    d = d.astype(np.float32)
     n_all = len(d)
     dev = torch.device("cuda", 0)
     rays = [torch.full((n_all,), float(pos[k]), device=dev) for k in range(3)]
@@ -50,7 +53,7 @@ def main():
     hits = [torch.zeros(n_all, dtype=torch.int32, device=dev) for _ in range(2)] + [torch.zeros(n_all, device=dev) for _ in range(3)]
     occ = torch.zeros(n_all, dtype=torch.uint8, device=dev)
     scene.set_option(rt.OPT_PROFILE, 1)
-    print("     n   event us | span us  bulk us  tail us | mean residency  waves  trips/wave")
+    print("     n   event us | span us  bulk us  tail us  last start us | mean residency  waves  trips/wave")
     for n in (1, 64, 1 << 10, 1 << 14, 1 << 16, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22):
         if n > n_all:
             break
@@ -74,7 +77,7 @@ def main():
         tick = 1e-2   # s_memtime runs at 100 MHz
         span = (t[3] - t[0]) * tick
         dry = (t[2] - t[0]) * tick if t[2] < (1 << 63) else span
-        print(f"{n:8d} {ms * 1e3:9.1f} | {span:7.1f} {dry:8.1f} {span - dry:8.1f} | {t[4] * tick / max(span, 1e-9) / 4096:10.2f} of 4096 {t[5]:6d} {t[7] / max(1, t[5]):9.1f}")
+        print(f"{n:8d} {ms * 1e3:9.1f} | {span:7.1f} {dry:8.1f} {span - dry:8.1f} {(t[1] - t[0]) * tick:8.1f} | {t[4] * tick / max(span, 1e-9) / 4096:10.2f} of 4096 {t[5]:6d} {t[7] / max(1, t[5]):9.1f}")
 
 
 if __name__ == "__main__":
