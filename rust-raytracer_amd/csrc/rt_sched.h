@@ -528,7 +528,6 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             ph = kt >= kn ? ST_TRI : ST_NODE;
           }
           DIAG_END(ph)
-          continue;
         }
         if (phase == ST_TNODE) {
           for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * TNODE_STAY_NUM && c > 0; c = wave_count(st == ST_TNODE)) {
@@ -549,7 +548,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 st = (enter || tree_done) ? ST_OBJ : ST_TNODE;
             }
           }
-        } else if (phase == ST_OBJ) {
+        }
+        if (phase == ST_OBJ) {
           // A lane stays in this phase across objects that end at once: a primitive that is not a mesh, or a mesh
           // whose root box the ray misses (most instances, for most rays): its root is tested right here.
           for (uint32_t c = c_obj; c * STAY_DEN >= c_obj * OBJ_STAY_NUM && c > 0; c = wave_count(st == ST_OBJ)) {
@@ -655,7 +655,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 }
             }
           }
-        } else {  // ST_FETCH
+        }
+        if (phase == ST_FETCH) {
             DIAG_STEP(ST_FETCH, c_fetch)
             const bool want = st == ST_FETCH;
             // hand out staged rays to the lanes that want one
