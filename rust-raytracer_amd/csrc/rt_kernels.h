@@ -15,11 +15,11 @@ static constexpr int STAGE_BLOCK = RTAMD_STAGE_BLOCK; // threads per block of th
 #define RTAMD_SCHED_WAVES 4
 #endif
 #ifndef RTAMD_NOMESH_WAVES
-#define RTAMD_NOMESH_WAVES 4
+#define RTAMD_NOMESH_WAVES 6
 #endif
-// scheduler kernels of scenes without meshes (mesh phases compiled out).  At 6 (three 8-wave blocks per CU, 80 VGPRs) the kernel
-// spills 14 registers and the scratch traffic costs more than the occupancy returns: 10 000 spheres 1 177 / 2 841 Mrays/s at
-// 1080x960 / 4K against 1 303 / 2 962 at 4 (and 1 174 / 2 446 at 5, which still fits only two blocks)
+// scheduler kernels of scenes without meshes (mesh phases compiled out): three 8-wave blocks per CU.  They need 74-82 VGPRs
+// and fit the 80 of six waves per SIMD without a spill since the loop's phases are a sequence of ifs (before that: 95-101,
+// 14 spilled at six, and two blocks per CU were faster).  10 000 spheres at 4K, 16 spp: 3 215 Mrays/s at 4, 3 560 at 5 and 6.
 static constexpr int NOMESH_WAVES_PER_SIMD = RTAMD_NOMESH_WAVES;
 static constexpr int SCHED_WAVES_PER_SIMD = RTAMD_SCHED_WAVES;  // register budget of the scheduler kernels: two 8-wave blocks per CU = 4 waves/SIMD, 128 VGPRs
 
