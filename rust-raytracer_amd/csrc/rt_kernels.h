@@ -8,9 +8,16 @@ namespace rtamd {
 
 static constexpr int TRACE_BLOCK = 512;  // threads per block of the traversal kernels (8 waves)
 #ifndef RTAMD_STAGE_BLOCK
-#define RTAMD_STAGE_BLOCK 1024
+#define RTAMD_STAGE_BLOCK 512
 #endif
-static constexpr int STAGE_BLOCK = RTAMD_STAGE_BLOCK; // threads per block of the queue-building stages (one queue atomic per block)
+// threads per block of the queue-building stages (one queue atomic per block).  The shade kernel is a long dependent chain with two
+// block-wide appends: two 512-thread blocks per CU overlap one block's barrier and atomic with the other's arithmetic (shade +
+// resolve 15.0 -> 14.5 ms per headline frame against one block of 1024; 256 costs more in queue atomics than it returns).
+static constexpr int STAGE_BLOCK = RTAMD_STAGE_BLOCK;
+#ifndef RTAMD_SHADE_WAVES
+#define RTAMD_SHADE_WAVES 4
+#endif
+static constexpr int SHADE_WAVES_PER_SIMD = RTAMD_SHADE_WAVES;  // register budget of the shade kernel
 #ifndef RTAMD_SCHED_WAVES
 #define RTAMD_SCHED_WAVES 4
 #endif

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
 // `T` is the shade set the launch fills.  Bounce 0 (`fold` != 0) reads the primary queue and starts the pixel's next
 // sample: fold 2 adds the radiance buffer's old content (the sample two passes back, complete by now) to the
 // pixel sum in generation order (integrator.rs:50-53), fold 1 and 2 zero the buffer; the throughput starts at 1.
-__global__ __launch_bounds__(STAGE_BLOCK) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
+__global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
                                                     uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot,
                                                     NextPass next) {
     __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
