@@ -87,55 +87,97 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene S, RayBatch 
 //   TAB_LDS: [mesh nodes | mesh triangles | objects (8 each) | ops (3 each) | cuboids (3 each) | root items (uint2)]
 //   TAB_MID: [mesh nodes | mesh triangles | classes (8 each) | cuboids (3 each) | tree headers (uint4) | root items (uint2)]
 enum : int { TAB_GLOBAL = 0, TAB_LDS = 1, TAB_MID = 2 };
+// Block-wide copy global -> LDS in two halves, so that the loads of several tables are all in flight before the first
+// store waits for one: `begin` issues up to D loads per thread, `end` stores them (and copies whatever lies beyond D
+// elements per thread one by one).  A trace launch starts with this copy in every block; as one load and one store per
+// loop trip it was a chain of a dozen memory round trips.
+template <int D, class T>
+__device__ __forceinline__ void block_copy_begin(T (&v)[D], const T* src, uint32_t n) {
+    if (n == 0u) {   // (nothing to read: src may be null)
+#pragma unroll
+        for (int k = 0; k < D; k++) v[k] = T{};
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        // (threads past the end re-read element 0: an unconditional load keeps v in registers)
+        const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
+        v[k] = src[i < n ? i : 0u];
+    }
+}
+template <int D, class T>
+__device__ __forceinline__ void block_copy_end(const T (&v)[D], T* dst, const T* src, uint32_t n) {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
+        if (i < n) dst[i] = v[k];
+    }
+    for (uint32_t i = threadIdx.x + (uint32_t)D * blockDim.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
 template <int MESHLOC, int TABKIND>
 __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, LdsTab& ltab, MidTab& mtab) {
     uint32_t base = 0;  // float4 offset
     lds.nodes = (lds_float4*)g_lds;
     lds.tris = (lds_float4*)g_lds;
-    if (MESHLOC == MESH_LDS || MESHLOC == MESH_MIXED) {
+    constexpr bool MESH = MESHLOC == MESH_LDS || MESHLOC == MESH_MIXED;
+    float4 vn[2], vt[8], va[1], vb[1], vc[1];
+    uint32_t n_node4 = 0, n_tri4 = 0;
+    const float4 *gn = nullptr, *gt = nullptr;
+    if (MESH) {
         const DevMesh m = S.meshes[S.lds_mesh];
-        const uint32_t n_node4 = 2 * m.n_nodes;
-        const uint32_t n_mesh4 = S.lds_bytes / 16;
-        const float4* gn = S.nodes + 2 * (size_t)m.node_base;
-        const float4* gt = S.tris + 3 * (size_t)m.tri_base;
-        for (uint32_t i = threadIdx.x; i < n_node4; i += blockDim.x) g_lds[i] = gn[i];
-        for (uint32_t i = threadIdx.x; i < n_mesh4 - n_node4; i += blockDim.x) g_lds[n_node4 + i] = gt[i];
+        n_node4 = 2 * m.n_nodes;
+        n_tri4 = S.lds_bytes / 16 - n_node4;
+        gn = S.nodes + 2 * (size_t)m.node_base;
+        gt = S.tris + 3 * (size_t)m.tri_base;
+        block_copy_begin(vn, gn, n_node4);
+        block_copy_begin(vt, gt, n_tri4);
         lds.tris = (lds_float4*)g_lds + n_node4;
-        base = n_mesh4;
+        base = n_node4 + n_tri4;
     }
     if (TABKIND == TAB_LDS) {
         const uint32_t n_obj4 = 8 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
         const float4* go = (const float4*)S.objects;
         const float4* gp = (const float4*)S.ops;
         const float4* gc = (const float4*)S.cuboids;
-        for (uint32_t i = threadIdx.x; i < n_obj4; i += blockDim.x) g_lds[base + i] = go[i];
-        for (uint32_t i = threadIdx.x; i < n_op4; i += blockDim.x) g_lds[base + n_obj4 + i] = gp[i];
-        for (uint32_t i = threadIdx.x; i < n_cub4; i += blockDim.x) g_lds[base + n_obj4 + n_op4 + i] = gc[i];
+        block_copy_begin(va, go, n_obj4);
+        block_copy_begin(vb, gp, n_op4);
+        block_copy_begin(vc, gc, n_cub4);
         uint2* lr = (uint2*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
         for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
+        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); block_copy_end(vt, g_lds + n_node4, gt, n_tri4); }
+        block_copy_end(va, g_lds + base, go, n_obj4);
+        block_copy_end(vb, g_lds + base + n_obj4, gp, n_op4);
+        block_copy_end(vc, g_lds + base + n_obj4 + n_op4, gc, n_cub4);
         ltab.S = &S;
         ltab.objects = (lds_float4*)g_lds + base;
         ltab.ops = (lds_float4*)g_lds + base + n_obj4;
         ltab.cuboids = (lds_float4*)g_lds + base + n_obj4 + n_op4;
         ltab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
-    }
-    if (TABKIND == TAB_MID) {
+    } else if (TABKIND == TAB_MID) {
         const uint32_t n_cls4 = 8 * S.n_classes, n_cub4 = 3 * S.n_cuboids, n_tree4 = S.n_trees;
         const float4* gk = (const float4*)S.classes;
         const float4* gc = (const float4*)S.cuboids;
-        const float4* gt = (const float4*)S.trees;
-        for (uint32_t i = threadIdx.x; i < n_cls4; i += blockDim.x) g_lds[base + i] = gk[i];
-        for (uint32_t i = threadIdx.x; i < n_cub4; i += blockDim.x) g_lds[base + n_cls4 + i] = gc[i];
-        for (uint32_t i = threadIdx.x; i < n_tree4; i += blockDim.x) g_lds[base + n_cls4 + n_cub4 + i] = gt[i];
+        const float4* gh = (const float4*)S.trees;
+        block_copy_begin(va, gk, n_cls4);
+        block_copy_begin(vb, gc, n_cub4);
+        block_copy_begin(vc, gh, n_tree4);
         uint2* lr = (uint2*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
         for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
+        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); block_copy_end(vt, g_lds + n_node4, gt, n_tri4); }
+        block_copy_end(va, g_lds + base, gk, n_cls4);
+        block_copy_end(vb, g_lds + base + n_cls4, gc, n_cub4);
+        block_copy_end(vc, g_lds + base + n_cls4 + n_cub4, gh, n_tree4);
         mtab.S = &S;
         mtab.classes = (lds_float4*)g_lds + base;
         mtab.cuboids = (lds_float4*)g_lds + base + n_cls4;
         mtab.trees = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4);
         mtab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
+    } else if (MESH) {
+        block_copy_end(vn, g_lds, gn, n_node4);
+        block_copy_end(vt, g_lds + n_node4, gt, n_tri4);
     }
-    if (MESHLOC == MESH_LDS || MESHLOC == MESH_MIXED || TABKIND != TAB_GLOBAL) __syncthreads();
+    if (MESH || TABKIND != TAB_GLOBAL) __syncthreads();
 }
 
 struct BatchIO {

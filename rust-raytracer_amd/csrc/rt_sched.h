@@ -51,6 +51,10 @@ static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
 #define RTAMD_OBJ_STAY_NUM 3
 #endif
 static constexpr uint32_t OBJ_STAY_NUM = RTAMD_OBJ_STAY_NUM;
+#ifndef RTAMD_OBJ_STAY_NUM_MESH
+#define RTAMD_OBJ_STAY_NUM_MESH 0
+#endif
+static constexpr uint32_t OBJ_STAY_NUM_MESH = RTAMD_OBJ_STAY_NUM_MESH;
 #ifndef RTAMD_TNODE_STAY_NUM
 #define RTAMD_TNODE_STAY_NUM 3
 #endif
@@ -552,7 +556,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         if (phase == ST_OBJ) {
           // A lane stays in this phase across objects that end at once: a primitive that is not a mesh, or a mesh
           // whose root box the ray misses (most instances, for most rays): its root is tested right here.
-          for (uint32_t c = c_obj; c * STAY_DEN >= c_obj * OBJ_STAY_NUM && c > 0; c = wave_count(st == ST_OBJ)) {
+          // (scenes without meshes: the OBJ step is the leaf work of the object tree and leaves early, at 3/4 of its lanes;
+          // with meshes most steps end at a missed root box and the phase is worth staying in until no lane is left: bunny
+          // scene +1 %, instanced grid +6 %, against -3 % for the sphere scene)
+          constexpr uint32_t obj_stay_num = MESHLOC == MESH_NONE ? OBJ_STAY_NUM : OBJ_STAY_NUM_MESH;
+          for (uint32_t c = c_obj; c * STAY_DEN >= c_obj * obj_stay_num && c > 0; c = wave_count(st == ST_OBJ)) {
             DIAG_STEP(ST_OBJ, c)
             DIAG_SUB_BEGIN
             if (st == ST_OBJ) {
