@@ -48,7 +48,7 @@ static constexpr uint32_t STAY_NUM = 3, STAY_DEN = 4;
 #define RTAMD_NODE_STAY_DEN 4
 #endif
 #ifndef RTAMD_OBJ_STAY_NUM
-#define RTAMD_OBJ_STAY_NUM 3
+#define RTAMD_OBJ_STAY_NUM 2
 #endif
 static constexpr uint32_t OBJ_STAY_NUM = RTAMD_OBJ_STAY_NUM;
 #ifndef RTAMD_OBJ_STAY_NUM_MESH
@@ -59,6 +59,10 @@ static constexpr uint32_t OBJ_STAY_NUM_MESH = RTAMD_OBJ_STAY_NUM_MESH;
 #define RTAMD_TNODE_STAY_NUM 3
 #endif
 static constexpr uint32_t TNODE_STAY_NUM = RTAMD_TNODE_STAY_NUM;
+#ifndef RTAMD_TNODE_STAY_NUM_MESH
+#define RTAMD_TNODE_STAY_NUM_MESH 1
+#endif
+static constexpr uint32_t TNODE_STAY_NUM_MESH = RTAMD_TNODE_STAY_NUM_MESH;
 static constexpr uint32_t NODE_STAY_NUM = RTAMD_NODE_STAY_NUM, NODE_STAY_DEN = RTAMD_NODE_STAY_DEN;
 // Vote weights (TRI, NODE, OBJ, FETCH, TNODE): a phase's lane count is multiplied by its weight before the
 // comparison, so a phase with a low weight waits until it has gathered proportionally more lanes.  The OBJ and
@@ -534,7 +538,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           DIAG_END(ph)
         }
         if (phase == ST_TNODE) {
-          for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * TNODE_STAY_NUM && c > 0; c = wave_count(st == ST_TNODE)) {
+          // (a tree of meshes: the lanes that leave for an object are gone for a whole mesh walk, the others are worth waiting
+          // for down to 1/4: instanced grid +8 %; a tree of spheres: 3/4, the objects are done in one OBJ step)
+          constexpr uint32_t tnode_stay_num = MESHLOC == MESH_NONE ? TNODE_STAY_NUM : TNODE_STAY_NUM_MESH;
+          for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * tnode_stay_num && c > 0; c = wave_count(st == ST_TNODE)) {
             DIAG_STEP(ST_TNODE, c)
             if (st == ST_TNODE) {
                 const float4* np = S.nodes + 2 * ((size_t)t_base + t_i);
@@ -556,7 +563,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         if (phase == ST_OBJ) {
           // A lane stays in this phase across objects that end at once: a primitive that is not a mesh, or a mesh
           // whose root box the ray misses (most instances, for most rays): its root is tested right here.
-          // (scenes without meshes: the OBJ step is the leaf work of the object tree and leaves early, at 3/4 of its lanes;
+          // (scenes without meshes: the OBJ step is the leaf work of the object tree and leaves early, at 1/2 of its lanes;
           // with meshes most steps end at a missed root box and the phase is worth staying in until no lane is left: bunny
           // scene +1 %, instanced grid +6 %, against -3 % for the sphere scene)
           constexpr uint32_t obj_stay_num = MESHLOC == MESH_NONE ? OBJ_STAY_NUM : OBJ_STAY_NUM_MESH;
