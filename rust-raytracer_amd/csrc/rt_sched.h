@@ -203,6 +203,12 @@ enum : uint32_t {
     F_FOUND = 64u,    // the current mesh walk accepted a triangle
     F_GENXF = 128u    // the current object's wrapper chain must be walked op by op
 };
+// max of two wave-uniform values on the scalar unit
+__device__ __forceinline__ uint32_t smax(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("s_max_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
 __device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t)__builtin_popcountll(__ballot(p)); }
 
 // Inclusive wave64 scans on the VALU's lane-crossing paths (no LDS round trips): four row_shr steps
@@ -487,7 +493,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           }
     };
     auto node_phase = [&](const uint32_t c_first) {
-          for (uint32_t c = c_first; c * NODE_STAY_DEN >= c_first * NODE_STAY_NUM && c > 0; c = wave_count(st == ST_NODE)) {
+          for (uint32_t c = c_first; c * NODE_STAY_DEN >= c_first * NODE_STAY_NUM && (NODE_STAY_NUM > 0u || c > 0u); c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
             if (st == ST_NODE) node_step();
           }
@@ -508,11 +514,12 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         // rays are scattered over them, and running a handful of mesh lanes first would serialise the wave: there
         // the weight applies only while at least VOTE_MESH_MIN lanes are in a mesh walk.
         const bool mesh_first = Tab::small_scene || c_tri + c_node >= VOTE_MESH_MIN;
+        // (the keys are wave-uniform; left to itself the compiler moves them into vector registers for a v_max3 and back)
         uint32_t key = ((c_tri * (mesh_first ? VOTE_W_TRI : 1u)) << 3) | ST_TRI;
-        key = max(key, ((c_node * (mesh_first ? VOTE_W_NODE : 1u)) << 3) | ST_NODE);
-        key = max(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
-        key = max(key, ((c_obj * VOTE_W_OBJ) << 3) | ST_OBJ);
-        key = max(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);
+        key = smax(key, ((c_node * (mesh_first ? VOTE_W_NODE : 1u)) << 3) | ST_NODE);
+        key = smax(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
+        key = smax(key, ((c_obj * VOTE_W_OBJ) << 3) | ST_OBJ);
+        key = smax(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);
         const uint32_t phase = key & 7u;
 
         if (MESHLOC != MESH_NONE && (phase == ST_TRI || phase == ST_NODE)) {
