@@ -1091,14 +1091,14 @@ struct DfParams {
 };
 enum : uint32_t { DF_ENTER = 0, DF_SCATTER = 1, DF_FOLD = 2 };
 
-__global__ __launch_bounds__(STAGE_BLOCK) void k_df_begin(WaveBufs W, DfParams X, uint32_t chunk_n, uint32_t out_base) {
-    __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
+__global__ __launch_bounds__(DF_BLOCK) void k_df_begin(WaveBufs W, DfParams X, uint32_t chunk_n, uint32_t out_base) {
+    __shared__ uint32_t sh_app[DF_BLOCK / 64 + 2];
     typedef CounterSlots CS;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cx = 0, cy = 0;
     const bool valid = i < chunk_n && slot_pixel(X.R, X.chunk_begin + i, cx, cy);
     uint32_t base, cnt;
-    const uint32_t q = block_append_range<STAGE_BLOCK / 64>(valid, &W.counts[out_base + CS::Q + 1], &W.counts[out_base + CS::Q], 1u, sh_app, base, cnt);
+    const uint32_t q = block_append_range<DF_BLOCK / 64>(valid, &W.counts[out_base + CS::Q + 1], &W.counts[out_base + CS::Q], 1u, sh_app, base, cnt);
     if (valid) {
         const Rng r = rng_seed((uint64_t)cx ^ __builtin_bswap64((uint64_t)cy));  // integrator.rs:36
         W.rng_lo[i] = r.lo; W.rng_hi[i] = r.hi;
@@ -1117,8 +1117,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_df_begin(WaveBufs W, DfParams X
     }
 }
 
-__global__ __launch_bounds__(STAGE_BLOCK) void k_df_step(DevScene S, WaveBufs W, DfParams X, uint32_t cur, uint32_t in_base, uint32_t out_base, uint32_t zero_base) {
-    __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
+__global__ __launch_bounds__(DF_BLOCK) void k_df_step(DevScene S, WaveBufs W, DfParams X, uint32_t cur, uint32_t in_base, uint32_t out_base, uint32_t zero_base) {
+    __shared__ uint32_t sh_app[DF_BLOCK / 64 + 2];
     typedef CounterSlots CS;
     const uint32_t n = W.counts[in_base + CS::Q + 1];
     if (blockIdx.x == 0)   // nothing reads or appends to that set before this launch is over
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_df_step(DevScene S, WaveBufs W,
         }
         // every lit hit emits the same number of shadow rays, so their queue positions follow from the block's range
         uint32_t lbase, lcnt;
-        const uint32_t lq = block_append_range<STAGE_BLOCK / 64>(lit, &W.counts[out_base + CS::LIT], &W.counts[out_base + CS::ANY], X.n_shoot, sh_app, lbase, lcnt);
+        const uint32_t lq = block_append_range<DF_BLOCK / 64>(lit, &W.counts[out_base + CS::LIT], &W.counts[out_base + CS::ANY], X.n_shoot, sh_app, lbase, lcnt);
         if (lit) {
             pend = (uint32_t)d + 1u;
             W.beta[slot] = diffuse.x; W.beta[slot + cap] = diffuse.y; W.beta[slot + 2 * cap] = diffuse.z;
@@ -1304,8 +1304,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_df_step(DevScene S, WaveBufs W,
             }
         }
         const bool still = active && !done;
-        const uint32_t ai = block_append<STAGE_BLOCK / 64>(still, &W.counts[out_base + CS::Q + 1], sh_app);
-        const uint32_t qi = block_append<STAGE_BLOCK / 64>(want_ray, &W.counts[out_base + CS::Q], sh_app);
+        const uint32_t ai = block_append<DF_BLOCK / 64>(still, &W.counts[out_base + CS::Q + 1], sh_app);
+        const uint32_t qi = block_append<DF_BLOCK / 64>(want_ray, &W.counts[out_base + CS::Q], sh_app);
         if (still) {
             act_out[ai] = slot;
             W.p_pix[slot] = make_uint2(pass, (uint32_t)d | (new_state << 8) | (pend << 16));
@@ -1470,18 +1470,18 @@ hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, con
 hipError_t launch_df_begin(const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t out_base, hipStream_t st) {
     if (chunk_n == 0) return hipSuccess;
     const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out};
-    const uint32_t g = (chunk_n + STAGE_BLOCK - 1) / STAGE_BLOCK;
-    hipLaunchKernelGGL(k_df_begin, dim3(g), dim3(STAGE_BLOCK), 0, st, W, X, chunk_n, out_base);
+    const uint32_t g = (chunk_n + DF_BLOCK - 1) / DF_BLOCK;
+    hipLaunchKernelGGL(k_df_begin, dim3(g), dim3(DF_BLOCK), 0, st, W, X, chunk_n, out_base);
     return hipGetLastError();
 }
 hipError_t launch_df_step(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t cur, uint32_t in_base,
                           uint32_t out_base, uint32_t zero_base, size_t upper, hipStream_t st) {
     const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out};
-    size_t need = (upper + STAGE_BLOCK - 1) / STAGE_BLOCK;
-    size_t capg = (size_t)cfg.num_cus * (2048 / STAGE_BLOCK);
+    size_t need = (upper + DF_BLOCK - 1) / DF_BLOCK;
+    size_t capg = (size_t)cfg.num_cus * (2048 / DF_BLOCK);
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
-    hipLaunchKernelGGL(k_df_step, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, X, cur, in_base, out_base, zero_base);
+    hipLaunchKernelGGL(k_df_step, dim3(g), dim3(DF_BLOCK), 0, st, S, W, X, cur, in_base, out_base, zero_base);
     return hipGetLastError();
 }
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st) {
