@@ -314,12 +314,15 @@ enum rtamd_option {
     RTAMD_OPT_STATIC_SHARE = 7, /* eighths (0..8) of a ray queue dealt to the waves up front; the rest is claimed dynamically.  Unless set,
                                    rtamd_upload_scene picks 6, or 3 for a scene with an object tree of >= 256 nodes */
     RTAMD_OPT_DEPTH_FIRST_ROUNDS = 9, /* scatter_rays != 1: 1 (default) rounds of one trace launch over every pixel's next ray, 0 one lane per pixel */
-    RTAMD_OPT_TREE_DEEPENING = 10 /* object trees of >= 256 nodes walked in passes of growing reach instead of once in the
+    RTAMD_OPT_TREE_DEEPENING = 10, /* object trees of >= 256 nodes walked in passes of growing reach instead of once in the
                                      reference's order, which is not front to back: 0 never; 1 (default) in rtamd_render*; 2 also in the
                                      batch entry points.  Same hits, with one exception: the reference reports a spurious hit at t = 0
                                      for a triangle its ray is parallel to within ~1e-7 rad (triangle.rs:26-28), wherever along the ray
                                      that triangle lies; a walk in passes reports the ray's real nearest hit when it finds one before
                                      its reach includes that triangle (measured: 2 of 16 million grazing rays) */
+    RTAMD_OPT_LEAN_KERNELS = 11   /* 1 (default): a scene that holds only meshes and cuboids (or only spheres and cuboids) under
+                                     Translate / Scale / Rotate chains runs traversal kernels compiled without the code for the other
+                                     object kinds and wrappers; 0: always the general kernels.  Same results, bit for bit */
 };
 int rtamd_set_option(rtamd_context* ctx, int option, int64_t value);
 /* Average duration (ms) and launch count of the closest-hit / any-hit trace kernels since the last

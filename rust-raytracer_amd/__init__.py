@@ -26,6 +26,7 @@ MISS = 0xFFFFFFFF
 OPT_PROFILE, OPT_MAX_PATHS, OPT_LDS_SCENE, OPT_SCHEDULER, OPT_CHUNK, OPT_BLOCKS_PER_CU, OPT_STREAMS, OPT_STATIC_SHARE, OPT_MIN_BATCH = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_DEPTH_FIRST_ROUNDS = 9
 OPT_TREE_DEEPENING = 10
+OPT_LEAN_KERNELS = 11
 
 _f32p = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)

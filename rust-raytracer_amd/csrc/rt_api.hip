@@ -400,6 +400,7 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
             return RTAMD_OK;
         case RTAMD_OPT_LDS_SCENE: ctx->cfg.use_lds = value != 0; return RTAMD_OK;
         case RTAMD_OPT_DEPTH_FIRST_ROUNDS: ctx->df_rounds = value != 0; return RTAMD_OK;
+        case RTAMD_OPT_LEAN_KERNELS: ctx->cfg.lean = value != 0 ? 1 : 0; return RTAMD_OK;
         case RTAMD_OPT_TREE_DEEPENING:
             if (value < 0 || value > 2) return fail(ctx, RTAMD_E_INVALID, "tree deepening mode must be 0, 1 or 2");
             ctx->deepen = (int)value; ctx->S.deepen = ctx->deepen >= 1 ? 1u : 0u;
@@ -724,6 +725,13 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
     S.any_box = 0;
     for (const DevObject& o : objects) S.any_box |= (o.xf_kind & XF_BOX) ? 1u : 0u;
+    S.features = 0;   // what the objects need besides mesh walks: picks the lean or the general form of the scheduler kernels
+    for (const DevObject& o : objects) {
+        if (o.geom_kind == GEOM_UNIT_SPHERE) S.features |= FEAT_SPHERE;
+        else if (o.geom_kind == GEOM_CUBOID) S.features |= FEAT_CUBOID;
+        else if (o.geom_kind != GEOM_MESH) S.features |= FEAT_OTHER;
+        if (o.xf_kind & XF_GENERIC) S.features |= FEAT_GENERIC_XF;
+    }
     // a root list of plain objects with consecutive indices is walked as one range, without reading the list
     S.root_first = MISS;
     if (sc->n_root > 0 && sc->root[0].kind == RTAMD_ROOT_OBJECT) {

@@ -68,6 +68,10 @@ struct DevLight { uint32_t kind; float vec[3]; float param; float emission[3]; }
 
 enum { OP_TRANSLATE = 0, OP_SCALE = 1, OP_ROTATE = 2, OP_BOUNDS = 3 };
 enum { GEOM_MESH = 0, GEOM_UNIT_SPHERE = 1, GEOM_CUBOID = 2, GEOM_UNIT_CUBOID = 3, GEOM_TRIANGLE = 4 };
+// What a scene's objects need besides mesh walks.  The scheduler kernels exist in a general form and in a lean one that is
+// compiled for the commonest mix only (see sched_features): code for kinds a scene does not hold costs a skipped region per
+// object visit even when no lane enters it.
+enum : uint32_t { FEAT_SPHERE = 1u, FEAT_CUBOID = 2u, FEAT_OTHER = 4u /* unit cuboid, standalone triangle */, FEAT_GENERIC_XF = 8u, FEAT_ALL = 15u };
 enum { ROOT_OBJECT = 0, ROOT_TREE = 1 };
 enum { MAT_NULL = 0, MAT_METAL = 1, MAT_GLOSSY = 2, MAT_TRANSPARENT = 3, MAT_LAMBERT = 4 };
 enum { LIGHT_AMBIENT = 0, LIGHT_POINT = 1, LIGHT_DIRECTION = 2, LIGHT_AO = 3 };
@@ -94,6 +98,7 @@ struct DevScene {
     uint32_t lds_bytes;       // bytes of LDS needed for that mesh
     uint32_t n_ops, n_cuboids;
     uint32_t any_box;         // some object carries XF_BOX: rays get their reciprocal direction when they are fetched
+    uint32_t features;        // FEAT_* bits of the object kinds and wrapper chains present
     uint32_t tab_bytes;       // bytes of LDS for the scene tables (objects, ops, cuboids, root), 0 = keep them in global memory
     // Large scenes (tab_bytes = 0): instance records of all objects in global memory, the classes and the small tables
     // (cuboids, trees, root list) in LDS.  mid_bytes = 0: not available (too many classes or cuboids).
@@ -486,15 +491,17 @@ struct Best {
 // Closest-hit test of a non-mesh primitive in object space: UnitSphere::hit (sphere.rs:36-45),
 // Cuboid::hit -> UnitCuboid::hit (cuboid.rs:82-93,19-28), Triangle::hit (triangle.rs:41-44).
 // u, v are only produced for the triangle; sphere / cuboid uv come from reconstruct_hit().
-template <class Tab>
+template <uint32_t FEAT = FEAT_ALL, class Tab>
 __device__ __forceinline__ bool primitive_closest(const DevScene& S, const Tab& tab, const ObjHead& ob, f3 pos, f3 dir, float t_max, float& t, float& u, float& v) {
-    if (ob.geom_kind == GEOM_UNIT_SPHERE) {
+    if ((FEAT & FEAT_SPHERE) && ob.geom_kind == GEOM_UNIT_SPHERE) {
         return unit_sphere_hit(pos, dir, t_max, t);
-    } else if (ob.geom_kind == GEOM_CUBOID) {
+    } else if ((FEAT & FEAT_CUBOID) && (ob.geom_kind == GEOM_CUBOID || (FEAT & (FEAT_SPHERE | FEAT_OTHER)) == 0u)) {   // (the only kind left)
         const CuboidRec c = tab.cuboid(ob.geom_index);
         f3 p = (pos - c.center) * c.inv_extent;  // cuboid.rs:83-85
         f3 d = dir * c.inv_extent;
         return unit_cuboid_hit(p, d, t_max, t);
+    } else if (!(FEAT & FEAT_OTHER)) {
+        return false;   // (not reached: the scene holds no other kind)
     } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {
         return unit_cuboid_hit(pos, dir, t_max, t);
     } else {  // GEOM_TRIANGLE
@@ -508,17 +515,19 @@ __device__ __forceinline__ bool primitive_closest(const DevScene& S, const Tab& 
 // Occlusion test of a non-mesh primitive: UnitSphere::is_hit (sphere.rs:63-69), Cuboid::is_hit
 // (cuboid.rs:95-100, world-space slab with Ray::inv_dir), UnitCuboid::is_hit (cuboid.rs:50-54),
 // Triangle::is_hit (triangle.rs:59-62).
-template <class Tab>
+template <uint32_t FEAT = FEAT_ALL, class Tab>
 __device__ __forceinline__ bool primitive_any(const DevScene& S, const Tab& tab, const ObjHead& ob, f3 pos, f3 dir, float t_max) {
-    if (ob.geom_kind == GEOM_UNIT_SPHERE) {
+    if ((FEAT & FEAT_SPHERE) && ob.geom_kind == GEOM_UNIT_SPHERE) {
         return unit_sphere_any(pos, dir, t_max);
-    } else if (ob.geom_kind == GEOM_CUBOID) {
+    } else if ((FEAT & FEAT_CUBOID) && (ob.geom_kind == GEOM_CUBOID || (FEAT & (FEAT_SPHERE | FEAT_OTHER)) == 0u)) {
         const CuboidRec c = tab.cuboid(ob.geom_index);
         f3 ctr = c.center, ext = c.extent;
         f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         float t0, t1;
         box_roots(pos, inv, ctr - ext, ctr + ext, t0, t1);
         return t0 <= t1 && t0 <= t_max && t1 >= 0.0f;
+    } else if (!(FEAT & FEAT_OTHER)) {
+        return false;   // (not reached: the scene holds no other kind)
     } else if (ob.geom_kind == GEOM_UNIT_CUBOID) {
         f3 inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         float t0, t1;

@@ -123,6 +123,7 @@ struct LaunchCfg {
     int min_batch = 4;             // rays per wave below which a short queue is not spread any thinner (1..64)
     int use_lds = 1;
     int scheduler = 1;             // 1: persistent phase-voting scheduler, 0: plain nested-loop kernels (batch entry points only)
+    int lean = 1;                  // 1: scenes of meshes + cuboids (or spheres + cuboids) under inline wrappers run the lean kernel form
 };
 
 hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st);

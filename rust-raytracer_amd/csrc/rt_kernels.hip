@@ -213,7 +213,7 @@ struct BatchIO {
     __device__ __forceinline__ void store_any(uint32_t i, uint32_t, bool occluded) const { any_out[i] = occluded ? 1 : 0; }
 };
 
-template <int MESHLOC, int TABKIND>
+template <int MESHLOC, int TABKIND, bool LEAN>
 __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD) void k_trace_batch_sched(DevScene S, BatchIO io, uint32_t n, uint32_t* work_head, uint32_t chunk) {
     {   // not even the block's first wave has a batch (see trace_scheduler)
         const uint32_t bs = sched_batch_size(n, gridDim.x * (TRACE_BLOCK / 64), tune_min_batch(chunk));
@@ -227,9 +227,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     stage_scene<MESHLOC, TABKIND>(S, lds, ltab, mtab);
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
     lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
-    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, work_head, n, chunk, stage, coop);
-    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC>(S, mtab, lds, io, work_head, n, chunk, stage, coop);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage, coop);
+    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, work_head, n, chunk, stage, coop);
+    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, work_head, n, chunk, stage, coop);
+    else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage, coop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -645,7 +645,7 @@ struct WaveIO {
     __device__ __forceinline__ void store_any(uint32_t i, uint32_t tag, bool occluded) const { (i >= n_a0 ? +vis1 : +vis0)[tag] = occluded ? 1 : 0; }
 };
 
-template <int MESHLOC, int TABKIND>
+template <int MESHLOC, int TABKIND, bool LEAN>
 __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
                                                             uint32_t a1_idx, uint32_t head_idx, uint32_t chunk_hint) {
     // queue lengths written by the previous stages (index MISS: that queue is absent)
@@ -674,9 +674,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     stage_scene<MESHLOC, TABKIND>(S, lds, ltab, mtab);
     WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.p_ray, W.set[0].a_ray, W.set[1].a_ray, W.set[0].a_vidx, W.set[1].a_vidx, W.h_rec, W.p_rec,
               W.set[0].vis, W.set[1].vis, W.cap, W.any_cap, n_q, n_closest, n_closest + n_a0};
-    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
-    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC>(S, mtab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
-    else trace_scheduler<MESHLOC>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
+    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
+    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
+    else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1350,21 +1350,28 @@ static inline int mesh_location(const DevScene& S, const LaunchCfg& cfg) {
     if (!cfg.use_lds || S.lds_mesh == MISS) return MESH_GLOBAL;
     return S.n_meshes == 1 ? MESH_LDS : MESH_MIXED;
 }
-#define RTAMD_DISPATCH_TAB(KERNEL, ML, tab, grid, lds_bytes, st, ...)                                                          \
+#define RTAMD_DISPATCH_LEAN(KERNEL, ML, TB, lean, grid, lds_bytes, st, ...)                                                    \
     do {                                                                                                                    \
-        if (tab == TAB_LDS) hipLaunchKernelGGL((KERNEL<ML, TAB_LDS>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);  \
-        else if (tab == TAB_MID) hipLaunchKernelGGL((KERNEL<ML, TAB_MID>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<ML, TAB_GLOBAL>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);         \
+        if (lean) hipLaunchKernelGGL((KERNEL<ML, TB, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<ML, TB, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);          \
     } while (0)
+#define RTAMD_DISPATCH_TAB(KERNEL, ML, tab, lean, grid, lds_bytes, st, ...)                                                    \
+    do {                                                                                                                    \
+        if (tab == TAB_LDS) RTAMD_DISPATCH_LEAN(KERNEL, ML, TAB_LDS, lean, grid, lds_bytes, st, __VA_ARGS__);                 \
+        else if (tab == TAB_MID) RTAMD_DISPATCH_LEAN(KERNEL, ML, TAB_MID, lean, grid, lds_bytes, st, __VA_ARGS__);            \
+        else RTAMD_DISPATCH_LEAN(KERNEL, ML, TAB_GLOBAL, lean, grid, lds_bytes, st, __VA_ARGS__);                             \
+    } while (0)
+// (lean_: the scene holds nothing beyond what the lean form of its kernel instance is compiled for, see sched_features)
 #define RTAMD_DISPATCH_MESHLOC(S, cfg, KERNEL, grid, st, ...)                                                                 \
     do {                                                                                                                    \
         const int loc_ = mesh_location(S, cfg);                                                                             \
         const int tab_ = !cfg.use_lds ? TAB_GLOBAL : ((S).tab_bytes > 0 ? TAB_LDS : ((S).mid_bytes > 0 ? TAB_MID : TAB_GLOBAL));  \
         const uint32_t lb_ = ((loc_ == MESH_LDS || loc_ == MESH_MIXED) ? (S).lds_bytes : 0u) + (tab_ == TAB_LDS ? (S).tab_bytes : (tab_ == TAB_MID ? (S).mid_bytes : 0u)); \
-        if (loc_ == MESH_NONE) RTAMD_DISPATCH_TAB(KERNEL, MESH_NONE, tab_, grid, lb_, st, __VA_ARGS__);                       \
-        else if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, grid, lb_, st, __VA_ARGS__);                    \
-        else if (loc_ == MESH_MIXED) RTAMD_DISPATCH_TAB(KERNEL, MESH_MIXED, tab_, grid, lb_, st, __VA_ARGS__);                \
-        else RTAMD_DISPATCH_TAB(KERNEL, MESH_GLOBAL, tab_, grid, lb_, st, __VA_ARGS__);                                       \
+        const bool lean_ = cfg.lean && ((S).features & ~sched_features(loc_, true)) == 0u;                                    \
+        if (loc_ == MESH_NONE) RTAMD_DISPATCH_TAB(KERNEL, MESH_NONE, tab_, lean_, grid, lb_, st, __VA_ARGS__);                \
+        else if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, lean_, grid, lb_, st, __VA_ARGS__);             \
+        else if (loc_ == MESH_MIXED) RTAMD_DISPATCH_TAB(KERNEL, MESH_MIXED, tab_, lean_, grid, lb_, st, __VA_ARGS__);         \
+        else RTAMD_DISPATCH_TAB(KERNEL, MESH_GLOBAL, tab_, lean_, grid, lb_, st, __VA_ARGS__);                                \
     } while (0)
 
 static inline uint32_t sched_chunk(const LaunchCfg& cfg, size_t n, uint32_t grid) {

@@ -244,12 +244,19 @@ __device__ __forceinline__ float lane_pull(uint32_t src_lane, float v) { return 
 static constexpr uint32_t COOP_WORDS = 64 + 128 + 192;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
-template <int MESHLOC, class Tab, class IO>
+// The lean form of a scheduler kernel serves scenes that hold nothing but what most scenes hold: meshes and cuboids under
+// inline wrapper chains (or, without meshes, spheres and cuboids).  Any other scene runs the general form.
+__host__ __device__ constexpr uint32_t sched_features(int meshloc, bool lean) {
+    return !lean ? FEAT_ALL : (meshloc == MESH_NONE ? (FEAT_SPHERE | FEAT_CUBOID) : FEAT_CUBOID);
+}
+template <int MESHLOC, bool LEAN, class Tab, class IO>
 __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
                                                 const uint32_t n_items, const uint32_t chunk_and_share, lds_u32* stage /* this wave's STAGE_WORDS */,
                                                 lds_u32* coop /* this wave's COOP_WORDS */) {
     const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = (chunk_and_share >> 16) & 0xFu;
     const uint32_t lane = lane_id();
+    constexpr uint32_t FEAT = sched_features(MESHLOC, LEAN);
+    constexpr bool GENERIC_XF = (FEAT & FEAT_GENERIC_XF) != 0u;
 
     uint32_t st = ST_FETCH, fl = 0;
     uint32_t ridx = 0, rtag = 0;
@@ -582,7 +589,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 if (MESHLOC != MESH_NONE && (fl & (F_PEND | F_FOUND)) == (F_PEND | F_FOUND)) {
                     best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
                     wtmax = otmax * oscale;
-                    if (fl & F_GENXF) { const ObjHead ob = tab.object(oi); wtmax = ops_t_out(tab, ob.op_first, ob.op_count, otmax); }
+                    if (GENERIC_XF && (fl & F_GENXF)) { const ObjHead ob = tab.object(oi); wtmax = ops_t_out(tab, ob.op_first, ob.op_count, otmax); }
                 }
                 fl &= ~(F_PEND | F_FOUND);
                 // (2) where does the next object come from?
@@ -641,12 +648,12 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     opos = wpos; otmax = tm_in;
                     odir = wdir;
                     oscale = ob.scale;
-                    if (ob.xf_kind & XF_GENERIC) {
+                    if (GENERIC_XF && (ob.xf_kind & XF_GENERIC)) {
                         fl |= F_GENXF;
                         // a BoundingBox wrapper that turns the ray away: go on as for a mesh without nodes
                         if (!ops_in(tab, ob.op_first, ob.op_count, opos, odir, otmax)) { ob.geom_kind = GEOM_MESH; ob.n_nodes = 0u; }
                     } else {
-                        fl &= ~F_GENXF;
+                        if (GENERIC_XF) fl &= ~F_GENXF;
                         xf_in_pos(ob.xf_kind, xf, ob.inv_scale, opos, otmax);
                         odir = xf_in_dir(ob.xf_kind, xf, wdir);
                     }
@@ -662,14 +669,14 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         float t = 0.0f;
                         bool hit;
                         if (fl & F_ANY) {
-                            hit = primitive_any(S, tab, ob, opos, odir, otmax);
+                            hit = primitive_any<FEAT>(S, tab, ob, opos, odir, otmax);
                             if (hit) { fl |= F_OCC | F_HAVE; st = ST_FETCH; }
                         } else {
                             float u = 0.f, v = 0.f;
-                            hit = primitive_closest(S, tab, ob, opos, odir, otmax, t, u, v);
+                            hit = primitive_closest<FEAT>(S, tab, ob, opos, odir, otmax, t, u, v);
                             if (hit) {
                                 best.obj = oi; best.prim = 0; best.t_local = t; best.u = u; best.v = v;
-                                wtmax = (fl & F_GENXF) ? ops_t_out(tab, ob.op_first, ob.op_count, t) : t * ob.scale;
+                                wtmax = (GENERIC_XF && (fl & F_GENXF)) ? ops_t_out(tab, ob.op_first, ob.op_count, t) : t * ob.scale;
                             }
                         }
                     }

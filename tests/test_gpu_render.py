@@ -183,6 +183,32 @@ def test_tuning_options_do_not_change_pixels(rt, sky):
         assert (st["closest_rays"], st["any_rays"]) == (st0["closest_rays"], st0["any_rays"])
 
 
+def test_lean_and_general_kernel_forms_agree(rt, sky):
+    """Scenes of meshes + cuboids, of instanced meshes in an object tree and of spheres + cuboids run the lean form of the traversal
+    kernels by default (compiled without the other object kinds and the op-by-op wrapper walk): the general form gives the same
+    hits, occlusion flags and pixels, bit for bit."""
+    rng = np.random.default_rng(5)
+    for scene in (rt.Scene.main(sky=sky, cam=(256, 192)), rt.Scene.grid(12, 9, sky=sky, cam=(256, 192)), rt.Scene.spheres(n=600, seed=3, sky=sky, cam=(256, 192))):
+        gpu = scene.upload(0)
+        n = 60000
+        pos = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+        pos[:, 2] = np.abs(pos[:, 2]) * 0.6 + 0.05
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.ascontiguousarray(np.concatenate([pos, d, np.full((n, 1), 1e12, np.float32)], axis=1).astype(np.float32).T)
+        lean_hit, lean_any = gpu.trace_closest(rays), gpu.trace_any(rays)
+        lean_img, lean_st = gpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+        gpu.set_option(rt.OPT_LEAN_KERNELS, 0)
+        full_hit, full_any = gpu.trace_closest(rays), gpu.trace_any(rays)
+        full_img, full_st = gpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
+        gpu.set_option(rt.OPT_LEAN_KERNELS, 1)
+        for k in ("obj", "prim", "t", "u", "v"):
+            assert np.array_equal(lean_hit[k].view(np.uint32), full_hit[k].view(np.uint32)), k
+        assert np.array_equal(lean_any, full_any)
+        assert np.array_equal(lean_img.view(np.uint32), full_img.view(np.uint32))
+        assert (lean_st["closest_rays"], lean_st["any_rays"]) == (full_st["closest_rays"], full_st["any_rays"])
+
+
 def test_quantizer_matches(rt, ol, pair):
     import torch
     gpu, _, _ = pair
