@@ -534,8 +534,13 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         // inline wrapper parameters when the chain is a subsequence of Translate, Scale, Rotate
         d.scale = 1.0f; d.inv_scale = 1.0f;
         uint32_t last = 0;
+        // Whether a hit can be carried out of the object from the inline parameters too (rotate, scale, then + off): every
+        // Translate of the chain, those by +0 included, must stand outside its Scale and Rotate, and adding +0 before the
+        // offset must not differ from adding the offset alone (it does for a -0 component: -0 + 0 + -0 = +0, -0 + -0 = -0).
+        bool any_translate = false, zero_translate = false, translate_inside = false;
         for (uint32_t k = 0; k < ob.op_count && d.xf_kind != XF_GENERIC; k++) {
             const rtamd_xform_op& op = sc->ops[ob.op_first + k];
+            if (op.kind == RTAMD_OP_TRANSLATE) { any_translate = true; translate_inside |= (d.xf_kind & (XF_S | XF_R)) != 0u; }
             // A Translate by (+0, +0, +0) leaves every ray position as it is, bit for bit (x - (+0) == x, also for -0, inf
             // and NaN): the reference's Transform always carries one (transform.rs:224-230), often with a zero offset
             // under another Translate.  It takes no part in entering the object; the hit is still carried out through
@@ -543,7 +548,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
             if (op.kind == RTAMD_OP_TRANSLATE) {
                 uint32_t bits[3];
                 std::memcpy(bits, op.v, 12);
-                if ((bits[0] | bits[1] | bits[2]) == 0u) continue;
+                if ((bits[0] | bits[1] | bits[2]) == 0u) { zero_translate = true; continue; }
             }
             const uint32_t bit = op.kind == RTAMD_OP_TRANSLATE ? XF_T : op.kind == RTAMD_OP_SCALE ? XF_S : op.kind == RTAMD_OP_ROTATE ? XF_R : XF_GENERIC;
             if (bit == XF_GENERIC || bit <= last) { d.xf_kind = XF_GENERIC; break; }
@@ -554,6 +559,11 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
             else std::memcpy(d.rot, op.v, 36);
         }
         if (d.xf_kind == XF_GENERIC) { d.scale = 1.0f; d.inv_scale = 1.0f; }
+        else {
+            bool minus_zero = false;
+            for (int c = 0; c < 3; c++) minus_zero |= d.off[c] == 0.0f && std::signbit(d.off[c]);
+            if (!translate_inside && !(zero_translate && minus_zero)) d.xf_kind |= XF_OUT_INLINE | (any_translate ? XF_T_OUT : 0u);
+        }
         object_box(sc, ob, nodes, meshes, d);
         objects.push_back(d);
     }

@@ -59,7 +59,9 @@ struct DevInst { float off[3]; float scale; float inv_scale; uint32_t cls; uint3
 static_assert(sizeof(DevInst) == 32, "instance record = 2 float4");
 static constexpr uint32_t CLS_NONE = 0xFFFFFFFFu;   // the object has no class: use its full record
 static constexpr uint32_t MAX_CLASSES = 32;
-enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8, XF_BOX = 16 /* test the object's box (bmin, bmax) before entering */ };
+enum : uint32_t { XF_T = 1, XF_S = 2, XF_R = 4, XF_GENERIC = 8, XF_BOX = 16 /* test the object's box (bmin, bmax) before entering */,
+                  XF_OUT_INLINE = 32 /* a hit is carried out of the object from the inline parameters as well (reconstruct_hit) */,
+                  XF_T_OUT = 64 /* ... adding `off` last: the chain holds a Translate, possibly only one by +0 */ };
 struct DevRootItem { uint32_t kind, index; };
 struct DevMaterial { uint32_t kind; float p0, p1; float color[3]; uint32_t tex_kind; int32_t tex_param; };
 struct DevImage { uint32_t first, w, h, pad; };   // texels at sky[first ...], row-major
@@ -666,7 +668,20 @@ __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b
     const GlobalTab tab{&S};
     const ObjHead ob = tab.object(b.obj);
     float unbounded = __builtin_huge_valf();   // the ray got through every BoundingBox wrapper when it was traced
-    (void)ops_in(tab, ob.op_first, ob.op_count, pos, dir, unbounded);
+    // A Translate -> Scale -> Rotate chain is applied from the object record's inline parameters, as the traversal does
+    // (the same operations in the same order): the record is one read, the op list a chain of dependent ones.
+    const bool inline_xf = !(ob.xf_kind & XF_GENERIC);
+    // (on the way out a Translate by +0, which takes no part in entering, still turns -0 into +0: the upload says whether the
+    // chain's way out is the inline parameters' too)
+    const bool inline_out = (ob.xf_kind & XF_OUT_INLINE) != 0u;
+    ObjXf xf;
+    if (inline_xf) {
+        xf = tab.object_xf(b.obj);
+        xf_in_pos(ob.xf_kind, xf, ob.inv_scale, pos, unbounded);
+        dir = xf_in_dir(ob.xf_kind, xf, dir);
+    } else {
+        (void)ops_in(tab, ob.op_first, ob.op_count, pos, dir, unbounded);
+    }
     f3 p, n;
     hu = b.u; hv = b.v;
     if (ob.geom_kind == GEOM_MESH) {
@@ -704,7 +719,13 @@ __device__ __forceinline__ void reconstruct_hit(const DevScene& S, const Best& b
         n = cross(mk(tr.b[0], tr.b[1], tr.b[2]) - a, mk(tr.c[0], tr.c[1], tr.c[2]) - a);
         p = pos + fill(b.t_local) * dir;
     }
-    ops_hit_out(tab, ob.op_first, ob.op_count, p, n);
+    if (inline_out) {   // ops_hit_out for that chain, innermost wrapper first
+        if (ob.xf_kind & XF_R) { p = mat_apply(xf.rot, p); n = mat_apply(xf.rot, n); }
+        if (ob.xf_kind & XF_S) p = p * ob.scale;
+        if (ob.xf_kind & XF_T_OUT) p = p + xf.off;
+    } else {
+        ops_hit_out(tab, ob.op_first, ob.op_count, p, n);
+    }
     hpos = p; hnorm = n;
 }
 
