@@ -96,6 +96,10 @@ static constexpr uint32_t NODE_STAY_NUM = RTAMD_NODE_STAY_NUM, NODE_STAY_DEN = R
 #define RTAMD_VOTE_MESH_MIN 16
 #endif
 static constexpr uint32_t VOTE_MESH_MIN = RTAMD_VOTE_MESH_MIN;
+#ifndef RTAMD_NODE_PAIRS
+#define RTAMD_NODE_PAIRS 1
+#endif
+static constexpr bool NODE_PAIRS = RTAMD_NODE_PAIRS != 0;   // mesh trees in global memory: two nodes per NODE step (node_step2)
 static constexpr uint32_t VOTE_W[5] = {RTAMD_VOTE_W};
 static constexpr uint32_t VOTE_W_OTHER_MAX = (VOTE_W[2] > VOTE_W[3] ? (VOTE_W[2] > VOTE_W[4] ? VOTE_W[2] : VOTE_W[4]) : (VOTE_W[3] > VOTE_W[4] ? VOTE_W[3] : VOTE_W[4]));
 static constexpr uint32_t VOTE_W_TRI = VOTE_W[0], VOTE_W_NODE = VOTE_W[1], VOTE_W_OBJ = VOTE_W[2], VOTE_W_FETCH = VOTE_W[3], VOTE_W_TNODE = VOTE_W[4];
@@ -377,6 +381,37 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         st = enter ? ST_TRI : (mesh_done ? ST_OBJ : ST_NODE);
     };
 
+    // Two nodes of the current mesh tree in one step, for trees in global memory: the node the walk stands on and the one
+    // stored behind it, which is where the walk goes next unless it enters a leaf or follows a skip link (a passed inner
+    // node, or a leaf that is missed or empty).  Both records are requested together (one L2 / HBM round trip, often one
+    // cache line) and tested against the same t_max: nothing between the two visits changes it, so the second test is the
+    // one the walk would make, and it is dropped when the walk does not go there.  Same visits in the same order as
+    // node_step twice.  (For a tree in LDS the second test costs what the saved step returns.)
+    auto node_step2 = [&]() {
+        const uint32_t i2 = n_i + 1u < n_n ? n_i + 1u : n_i;   // (the last node has nothing behind it)
+        const float4* np = S.nodes + 2 * ((size_t)node_off + n_i);
+        const float4* mp = S.nodes + 2 * ((size_t)node_off + i2);
+        const float4 n0 = np[0], n1 = np[1], m0 = mp[0], m1 = mp[1];
+        const bool sx = signbit32(oinv.x), sy = signbit32(oinv.y), sz = signbit32(oinv.z);
+        const uint32_t A1 = __float_as_uint(n1.z), B1 = __float_as_uint(n1.w), A2 = __float_as_uint(m1.z), B2 = __float_as_uint(m1.w);
+        const bool leaf1 = (A1 & LEAF_BIT) != 0u, leaf2 = (A2 & LEAF_BIT) != 0u;
+        const uint32_t first1 = A1 & ~LEAF_BIT, first2 = A2 & ~LEAF_BIT;
+        const bool pass1 = node_passes(n0, n1, opos, oinv, sx, sy, sz, otmax);
+        const bool pass2 = node_passes(m0, m1, opos, oinv, sx, sy, sz, otmax);
+        const bool enter1 = pass1 && leaf1 && first1 < B1;
+        const bool on = !enter1 && (pass1 || leaf1) && n_i + 1u < n_n;   // the walk goes on to the node behind
+        const bool enter2 = on && pass2 && leaf2 && first2 < B2;
+        const uint32_t next1 = (pass1 || leaf1) ? n_i + 1u : A1;        // skip link on a failed inner node
+        const uint32_t next2 = enter2 ? n_i + 1u : ((pass2 || leaf2) ? n_i + 2u : A2);
+        const bool enter = enter1 || enter2;
+        k_cur = enter1 ? first1 : (enter2 ? first2 : k_cur);
+        k_end = enter1 ? B1 : (enter2 ? B2 : k_end);
+        n_i = enter1 ? n_i : (on ? next2 : next1);
+        const bool mesh_done = !enter && n_i >= n_n;
+        fl |= mesh_done ? F_PEND : 0u;
+        st = enter ? ST_TRI : (mesh_done ? ST_OBJ : ST_NODE);
+    };
+
     DIAG_DECL
     TL_DECL
     auto tri_phase = [&]() {
@@ -502,7 +537,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     auto node_phase = [&](const uint32_t c_first) {
           for (uint32_t c = c_first; c * NODE_STAY_DEN >= c_first * NODE_STAY_NUM && (NODE_STAY_NUM > 0u || c > 0u); c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
-            if (st == ST_NODE) node_step();
+            if (st == ST_NODE) { if (NODE_PAIRS && MESHLOC == MESH_GLOBAL) node_step2(); else node_step(); }
           }
     };
     for (;;) {
