@@ -381,7 +381,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         st = enter ? ST_TRI : (mesh_done ? ST_OBJ : ST_NODE);
     };
 
-    // Two nodes of the current mesh tree in one step, for trees in global memory: the node the walk stands on and the one
+    // Two nodes of the current mesh tree in one step, for scenes with trees in global memory: the node the walk stands on and the one
     // stored behind it, which is where the walk goes next unless it enters a leaf or follows a skip link (a passed inner
     // node, or a leaf that is missed or empty).  Both records are requested together (one L2 / HBM round trip, often one
     // cache line) and tested against the same t_max: nothing between the two visits changes it, so the second test is the
@@ -389,9 +389,16 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     // node_step twice.  (For a tree in LDS the second test costs what the saved step returns.)
     auto node_step2 = [&]() {
         const uint32_t i2 = n_i + 1u < n_n ? n_i + 1u : n_i;   // (the last node has nothing behind it)
-        const float4* np = S.nodes + 2 * ((size_t)node_off + n_i);
-        const float4* mp = S.nodes + 2 * ((size_t)node_off + i2);
-        const float4 n0 = np[0], n1 = np[1], m0 = mp[0], m1 = mp[1];
+        float4 n0, n1, m0, m1;
+        if (MESHLOC == MESH_MIXED && (fl & F_MLDS)) {   // (a mixed scene's lanes on the LDS-resident mesh take the same step)
+            lds_float4* np = lds.nodes + 2 * n_i;
+            lds_float4* mp = lds.nodes + 2 * i2;
+            n0 = lds_load4(np); n1 = lds_load4(np + 1); m0 = lds_load4(mp); m1 = lds_load4(mp + 1);
+        } else {
+            const float4* np = S.nodes + 2 * ((size_t)node_off + n_i);
+            const float4* mp = S.nodes + 2 * ((size_t)node_off + i2);
+            n0 = np[0]; n1 = np[1]; m0 = mp[0]; m1 = mp[1];
+        }
         const bool sx = signbit32(oinv.x), sy = signbit32(oinv.y), sz = signbit32(oinv.z);
         const uint32_t A1 = __float_as_uint(n1.z), B1 = __float_as_uint(n1.w), A2 = __float_as_uint(m1.z), B2 = __float_as_uint(m1.w);
         const bool leaf1 = (A1 & LEAF_BIT) != 0u, leaf2 = (A2 & LEAF_BIT) != 0u;
@@ -537,7 +544,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     auto node_phase = [&](const uint32_t c_first) {
           for (uint32_t c = c_first; c * NODE_STAY_DEN >= c_first * NODE_STAY_NUM && (NODE_STAY_NUM > 0u || c > 0u); c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
-            if (st == ST_NODE) { if (NODE_PAIRS && MESHLOC == MESH_GLOBAL) node_step2(); else node_step(); }
+            if (st == ST_NODE) { if (NODE_PAIRS && (MESHLOC == MESH_GLOBAL || MESHLOC == MESH_MIXED)) node_step2(); else node_step(); }
           }
     };
     for (;;) {
