@@ -970,8 +970,10 @@ int render_depth_first_rounds(rtamd_context* ctx, const rtamd_camera* cam, const
     WaveBufs W = ws.W;
     W.cap = (uint32_t)ws.cap;
     hipStream_t st = ws.stream;
+    // (the frame stack is laid out for `cap` slots, whatever the capacity of the workspace, which an earlier render may have
+    // left larger)
     DfFrame F{make_region(*region), make_camera(*cam), (uint32_t)integ->antialiasing, D, integ->shadow_rays, integ->scatter_rays, S_shoot,
-              (float*)ctx->batch_buf, out};
+              (float*)ctx->batch_buf, out, (uint32_t)cap};
     hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
     HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ev0, 0));

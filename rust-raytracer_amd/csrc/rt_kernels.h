@@ -165,6 +165,7 @@ struct DfFrame {
     uint32_t n_shoot;   // shadow rays per lit hit
     float* stack;
     float* out;
+    uint32_t stack_cap;   // slots per depth level of `stack`
 };
 hipError_t launch_df_begin(const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t out_base, hipStream_t st);
 hipError_t launch_df_step(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t cur, uint32_t in_base,

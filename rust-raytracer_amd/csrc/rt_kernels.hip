@@ -1086,8 +1086,10 @@ struct DfParams {
     uint32_t chunk_begin, aa;
     int32_t max_depth, shadow_rays, scatter_rays;
     uint32_t n_shoot;
-    float* stack;   // max_depth * PathFrame::WORDS * cap
+    float* stack;   // max_depth * PathFrame::WORDS * stack_cap
     float* out;
+    uint32_t stack_cap;   // slots the frame stack is laid out for: the chunk size of this render, which can be smaller than the
+                          // capacity of a workspace that an earlier, larger render left behind (W.cap)
 };
 enum : uint32_t { DF_ENTER = 0, DF_SCATTER = 1, DF_FOLD = 2 };
 
@@ -1168,8 +1170,8 @@ __global__ __launch_bounds__(DF_BLOCK) void k_df_step(DevScene S, WaveBufs W, Df
                     illum = illum + tot / (float)ns;
                 }
                 const f3 c = fill(0.0f) + df * illum;
-                float* q = X.stack + (size_t)(pend_in - 1u) * PathFrame::WORDS * cap + slot;
-                q[0] = c.x; q[cap] = c.y; q[2 * (size_t)cap] = c.z;
+                float* q = X.stack + (size_t)(pend_in - 1u) * PathFrame::WORDS * X.stack_cap + slot;
+                q[0] = c.x; q[X.stack_cap] = c.y; q[2 * (size_t)X.stack_cap] = c.z;   // (the frame's colour: its first three words)
             }
             if (state == DF_ENTER) {               // the closest-hit ray of integrate_recur(ray, d) is back, integrator.rs:64
                 const uint32_t qi = W.p_slot[slot];
@@ -1200,7 +1202,7 @@ __global__ __launch_bounds__(DF_BLOCK) void k_df_step(DevScene S, WaveBufs W, Df
                     in_scatter = true;
                 }
             } else {
-                frame_load(X.stack, cap, slot, d, f);
+                frame_load(X.stack, X.stack_cap, slot, d, f);
                 if (state == DF_FOLD) {            // a scatter ray's radiance waited for this frame's colour, integrator.rs:98
                     ret = mk(ret_buf[slot], ret_buf[slot + cap], ret_buf[slot + 2 * cap]);
                     f.color = f.color + (f.w * ret) / n_scatter;
@@ -1259,13 +1261,13 @@ __global__ __launch_bounds__(DF_BLOCK) void k_df_step(DevScene S, WaveBufs W, Df
                         }
                     }
                     if (descend) {
-                        frame_store(X.stack, cap, slot, d, f);
+                        frame_store(X.stack, X.stack_cap, slot, d, f);
                         d++;
                         if (d < X.max_depth) { want_ray = true; new_state = DF_ENTER; break; }
                         ret = sky_color(S, rdir);                   // integrator.rs:59-61: the depth limit ends the path without a ray
                         in_return = true;
                     } else {
-                        if (pend == (uint32_t)d + 1u) { frame_store(X.stack, cap, slot, d, f); new_state = DF_SCATTER; break; }
+                        if (pend == (uint32_t)d + 1u) { frame_store(X.stack, X.stack_cap, slot, d, f); new_state = DF_SCATTER; break; }
                         ret = f.color;
                         in_return = true;
                     }
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(DF_BLOCK) void k_df_step(DevScene S, WaveBufs W, Df
                         new_state = DF_FOLD;
                         break;
                     }
-                    frame_load(X.stack, cap, slot, d, f);
+                    frame_load(X.stack, X.stack_cap, slot, d, f);
                     f.color = f.color + (f.w * ret) / n_scatter;
                     in_scatter = true;
                 }
@@ -1476,14 +1478,14 @@ hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, con
 }
 hipError_t launch_df_begin(const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t out_base, hipStream_t st) {
     if (chunk_n == 0) return hipSuccess;
-    const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out};
+    const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out, F.stack_cap};
     const uint32_t g = (chunk_n + DF_BLOCK - 1) / DF_BLOCK;
     hipLaunchKernelGGL(k_df_begin, dim3(g), dim3(DF_BLOCK), 0, st, W, X, chunk_n, out_base);
     return hipGetLastError();
 }
 hipError_t launch_df_step(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t cur, uint32_t in_base,
                           uint32_t out_base, uint32_t zero_base, size_t upper, hipStream_t st) {
-    const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out};
+    const DfParams X{F.R, F.cam, chunk_begin, F.aa, F.max_depth, F.shadow_rays, F.scatter_rays, F.n_shoot, F.stack, F.out, F.stack_cap};
     size_t need = (upper + DF_BLOCK - 1) / DF_BLOCK;
     size_t capg = (size_t)cfg.num_cus * (2048 / DF_BLOCK);
     uint32_t g = (uint32_t)(need < capg ? need : capg);

@@ -183,6 +183,21 @@ def test_tuning_options_do_not_change_pixels(rt, sky):
         assert (st["closest_rays"], st["any_rays"]) == (st0["closest_rays"], st0["any_rays"])
 
 
+def test_depth_first_rounds_in_chunks_smaller_than_an_earlier_workspace(rt, sky):
+    """scatter_rays != 1 rendered in chunks (RTAMD_OPT_MAX_PATHS) on a context whose wavefront workspace an earlier, larger
+    render has left behind: the frame stack is laid out for the chunk, not for the workspace's capacity.  Same pixels and
+    ray counts as the frame rendered in one piece."""
+    params = dict(max_depth=3, shadow_rays=1, scatter_rays=2, antialiasing=2)
+    ref, st0 = rt.Scene.main(sky=sky, cam=(128, 96)).upload(0).render(**params)   # one chunk, a context of its own
+    gpu = rt.Scene.main(sky=sky, cam=(128, 96)).upload(0)
+    gpu.render(max_depth=2, shadow_rays=1, scatter_rays=1, antialiasing=1)        # wavefront render: a workspace for the whole frame
+    gpu.set_option(rt.OPT_MAX_PATHS, 2500)
+    img, st = gpu.render(**params)                                                # five chunks in that workspace
+    gpu.set_option(rt.OPT_MAX_PATHS, 1 << 22)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert (st["closest_rays"], st["any_rays"]) == (st0["closest_rays"], st0["any_rays"])
+
+
 def test_lean_and_general_kernel_forms_agree(rt, sky):
     """Scenes of meshes + cuboids, of instanced meshes in an object tree and of spheres + cuboids run the lean form of the traversal
     kernels by default (compiled without the other object kinds and the op-by-op wrapper walk): the general form gives the same
