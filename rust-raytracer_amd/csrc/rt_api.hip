@@ -107,8 +107,9 @@ int upload_vec(rtamd_context* ctx, const std::vector<T>& host, const T** dev) {
 }
 
 // Reference layout (AABB, skip, first) + sentinel  ->  device nodes (see rt_device.h).
+// *plain is cleared when a box is not finite or has min > max on some axis (what the kernels' NaN-free box test presumes).
 int convert_tree(rtamd_context* ctx, const rtamd_bvh_node* nodes, uint32_t n_nodes, uint32_t n_prims, const char* what,
-                 std::vector<float4>& out) {
+                 std::vector<float4>& out, bool* plain = nullptr) {
     if (nodes == nullptr || n_nodes < 2) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": a tree needs at least one node and the sentinel");
     uint32_t n = n_nodes - 1;
     if (nodes[n].first != n_prims) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": sentinel.first must equal the primitive count");
@@ -122,6 +123,9 @@ int convert_tree(rtamd_context* ctx, const rtamd_bvh_node* nodes, uint32_t n_nod
         uint32_t A = leaf ? (LEAF_BIT | first) : nd.skip;
         uint32_t B = leaf ? end : 0u;
         if (leaf && (first & LEAF_BIT)) return fail(ctx, RTAMD_E_INVALID, std::string(what) + ": too many primitives");
+        if (plain)
+            for (int k = 0; k < 3; k++)
+                if (!(std::isfinite(nd.min[k]) && std::isfinite(nd.max[k]) && nd.min[k] <= nd.max[k])) *plain = false;
         float fa, fb;
         std::memcpy(&fa, &A, 4);
         std::memcpy(&fb, &B, 4);
@@ -464,6 +468,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     std::vector<float4> nodes, tris, normals;
     std::vector<DevMesh> meshes;
     std::vector<DevTree> trees;
+    bool plain_boxes = true;   // every mesh-tree box finite with min <= max
     int rc;
     {
         size_t nn = 0, nt = 0, nv = 0;
@@ -479,7 +484,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         dm.n_nodes = me.n_nodes ? me.n_nodes - 1 : 0;
         dm.tri_base = (uint32_t)(tris.size() / 3);
         dm.normal_base = (uint32_t)normals.size();
-        if ((rc = convert_tree(ctx, me.nodes, me.n_nodes, me.n_tris, "mesh tree", nodes))) return rc;
+        if ((rc = convert_tree(ctx, me.nodes, me.n_nodes, me.n_tris, "mesh tree", nodes, &plain_boxes))) return rc;
         for (uint32_t k = 0; k < me.n_tris; k++) {
             uint32_t i0 = me.tri_indices[3 * k], i1 = me.tri_indices[3 * k + 1], i2 = me.tri_indices[3 * k + 2];
             if (i0 >= me.n_verts || i1 >= me.n_verts || i2 >= me.n_verts) return fail(ctx, RTAMD_E_INVALID, "triangle vertex index out of bounds");
@@ -733,6 +738,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     }
     // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
+    S.plain_boxes = plain_boxes ? 1u : 0u;
     S.any_box = 0;
     for (const DevObject& o : objects) S.any_box |= (o.xf_kind & XF_BOX) ? 1u : 0u;
     S.features = 0;   // what the objects need besides mesh walks: picks the lean or the general form of the scheduler kernels

@@ -1340,7 +1340,10 @@ static inline uint32_t trace_grid(const LaunchCfg& cfg, size_t n) {
 }
 
 static inline uint32_t sched_grid(const LaunchCfg& cfg, size_t upper, bool no_mesh = false) {
-    size_t need = (upper + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    // a queue too short to give every wave of the full grid 64 rays is spread thinner, down to min_batch rays per wave
+    // (sched_batch_size), the first wave of every block before any block's second: as many blocks as such batches
+    const size_t mb = (size_t)(cfg.min_batch < 1 ? 1 : (cfg.min_batch > 64 ? 64 : cfg.min_batch));
+    size_t need = (upper + mb - 1) / mb;
     // scenes without meshes run the leaner kernel instance at a higher occupancy: half as many blocks again per CU
     size_t cap = (size_t)cfg.num_cus * (no_mesh ? (cfg.sched_blocks_per_cu * NOMESH_WAVES_PER_SIMD + SCHED_WAVES_PER_SIMD - 1) / SCHED_WAVES_PER_SIMD : cfg.sched_blocks_per_cu);
     size_t g = need < cap ? need : cap;

@@ -26,7 +26,7 @@
 
 namespace rtamd {
 
-enum : uint32_t { ST_FETCH = 0, ST_OBJ = 1, ST_TNODE = 2, ST_NODE = 3, ST_TRI = 4, ST_DONE = 5 };
+enum : uint32_t { ST_FETCH = 0, ST_OBJ = 1, ST_TNODE = 2, ST_NODE = 3, ST_TRI = 4, ST_DONE = 5, ST_WALK = 6 /* walks its mesh by itself */ };
 
 // LDS copy of mesh S.lds_mesh, addressed through LDS-typed pointers so that the loads are
 // ds_read_b128 (a generic pointer that may be LDS or global compiles to slow flat loads).
@@ -100,6 +100,11 @@ static constexpr uint32_t VOTE_MESH_MIN = RTAMD_VOTE_MESH_MIN;
 #define RTAMD_NODE_PAIRS 1
 #endif
 static constexpr bool NODE_PAIRS = RTAMD_NODE_PAIRS != 0;
+#ifndef RTAMD_PLAIN_NODE
+#define RTAMD_PLAIN_NODE 1
+#endif
+// mesh-tree boxes of rays that cannot produce a NaN are tested with plain minima and maxima (node_passes_plain)
+static constexpr bool PLAIN_NODE = RTAMD_PLAIN_NODE != 0;
 #ifndef RTAMD_TNODE_PAIRS
 #define RTAMD_TNODE_PAIRS 1
 #endif
@@ -366,6 +371,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
 
     // One node of the current mesh tree (bvh.rs:227-252): visit test, then into the leaf, on to the next
     // node, or along the skip link.  Used by the NODE phase and, for a mesh's root, by the OBJ phase.
+    // (PLAIN_NODE: a ray whose slab products could be NaNs never gets here; its mesh walk is done where it enters the mesh)
     auto node_step = [&]() {
         float4 n0, n1;
         if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && (fl & F_MLDS))) {
@@ -378,7 +384,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
         const bool leaf = (A & LEAF_BIT) != 0u;
         const uint32_t first = A & ~LEAF_BIT;
-        const bool pass = node_passes(n0, n1, opos, oinv, signbit32(oinv.x), signbit32(oinv.y), signbit32(oinv.z), otmax);
+        const bool pass = PLAIN_NODE ? node_passes_plain(n0, n1, opos, oinv, otmax)
+                                     : node_passes(n0, n1, opos, oinv, signbit32(oinv.x), signbit32(oinv.y), signbit32(oinv.z), otmax);
         const bool enter = pass && leaf && first < B;
         k_cur = enter ? first : k_cur; k_end = enter ? B : k_end;
         n_i = enter ? n_i : ((pass || leaf) ? n_i + 1 : A);   // skip link on a failed inner node
@@ -409,8 +416,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t A1 = __float_as_uint(n1.z), B1 = __float_as_uint(n1.w), A2 = __float_as_uint(m1.z), B2 = __float_as_uint(m1.w);
         const bool leaf1 = (A1 & LEAF_BIT) != 0u, leaf2 = (A2 & LEAF_BIT) != 0u;
         const uint32_t first1 = A1 & ~LEAF_BIT, first2 = A2 & ~LEAF_BIT;
-        const bool pass1 = node_passes(n0, n1, opos, oinv, sx, sy, sz, otmax);
-        const bool pass2 = node_passes(m0, m1, opos, oinv, sx, sy, sz, otmax);
+        const bool pass1 = PLAIN_NODE ? node_passes_plain(n0, n1, opos, oinv, otmax) : node_passes(n0, n1, opos, oinv, sx, sy, sz, otmax);
+        const bool pass2 = PLAIN_NODE ? node_passes_plain(m0, m1, opos, oinv, otmax) : node_passes(m0, m1, opos, oinv, sx, sy, sz, otmax);
         const bool enter1 = pass1 && leaf1 && first1 < B1;
         const bool on = !enter1 && (pass1 || leaf1) && n_i + 1u < n_n;   // the walk goes on to the node behind
         const bool enter2 = on && pass2 && leaf2 && first2 < B2;
@@ -562,7 +569,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t c_tnode = wave_count(st == ST_TNODE);
         const uint32_t c_obj = wave_count(st == ST_OBJ);
         const uint32_t c_fetch = wave_count(st == ST_FETCH);
-        if ((c_tri | c_node | c_tnode | c_obj | c_fetch) == 0) break;  // every lane is ST_DONE
+        const uint32_t c_walk = (PLAIN_NODE && MESHLOC != MESH_NONE) ? wave_count(st == ST_WALK) : 0u;
+        if ((c_tri | c_node | c_tnode | c_obj | c_fetch | c_walk) == 0) break;  // every lane is ST_DONE
         // most lanes wins; ties go to the deeper phase (the state codes grow with depth)
         // The mesh phases always get their weight in a small scene (its tables fit LDS): the rays walk few objects
         // in much the same order, so the mesh walks of a wave coincide.  In a scene of thousands of instances the
@@ -575,7 +583,25 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         key = smax(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
         key = smax(key, ((c_obj * VOTE_W_OBJ) << 3) | ST_OBJ);
         key = smax(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);
-        const uint32_t phase = key & 7u;
+        const uint32_t phase = c_walk ? (uint32_t)ST_WALK : key & 7u;   // (rare, and gone after one step)
+
+        if (PLAIN_NODE && MESHLOC != MESH_NONE && phase == ST_WALK) {
+            // The boxes of a mesh tree are tested with plain minima and maxima (node_passes_plain), which presumes that no slab
+            // product is a NaN.  A ray for which one can be (a direction component of exactly zero, a non-finite origin, a tree
+            // with a box that is not finite) needs the reference's NaN rules at every box: such rays are rare, and the lane
+            // walks the whole mesh here, by itself, through global memory, as the plain kernels do.  A closest-hit walk also
+            // answers an occlusion query: until its first accepted triangle it is the same walk.
+            if (st == ST_WALK) {
+                const GlobalMem gm{S.nodes + 2 * (size_t)node_off, S.tris + 3 * (size_t)tri_off};
+                float tm = otmax, hu = 0.0f, hv = 0.0f;
+                uint32_t prim = 0u;
+                st = ST_OBJ;
+                if (traverse_mesh<false>(gm, n_n, opos, odir, tm, prim, hu, hv)) {
+                    if (fl & F_ANY) { fl |= F_OCC | F_HAVE; st = ST_FETCH; }
+                    else { otmax = tm; oprim = prim; ou = hu; ov = hv; fl |= F_PEND | F_FOUND; }
+                }
+            }
+        }
 
         if (MESHLOC != MESH_NONE && (phase == ST_TRI || phase == ST_NODE)) {
           // The two mesh phases alternate many times between two steps of any other phase, and they change only a few of
@@ -740,7 +766,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
                         if (MESHLOC == MESH_MIXED) fl = (ob.geom_index == S.lds_mesh) ? (fl | F_MLDS) : (fl & ~F_MLDS);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
-                        if (n_n > 0) node_step();
+                        // a ray (or a tree) for which a slab product can be a NaN takes the WALK phase instead of the mesh phases
+                        if (PLAIN_NODE && !(S.plain_boxes != 0u && plain_ray(opos, oinv))) st = ST_WALK;
+                        else if (n_n > 0) node_step();
                         DIAG_SUB_END(5)
                     } else {
                         float t = 0.0f;

@@ -175,6 +175,20 @@ def test_two_mesh_scene_with_coplanar_duplicates(rt, ol, sky, n, with_bunny):
     check_closest(rt, gpu.trace_closest(down), ref)
     on_field = ref["obj"] == 0
     assert on_field.mean() > 0.6
+    # straight down along the grid lines: the origin lies in the planes of the tree's boxes, where a slab product is
+    # 0 x inf = NaN and the reference's min! / max! rules decide (the vertex columns are reproduced in f32 as the scene makes them)
+    cell = np.float32(12.0) / np.float32(n)
+    lines = np.float32(-6.0) + cell * np.arange(n + 1, dtype=np.float32)
+    ex, ey = np.meshgrid(lines, xs.astype(np.float32))
+    cx, cy = np.meshgrid(lines, lines)
+    edge = np.zeros((7, 2 * ex.size + cx.size), np.float32)
+    edge[0] = np.concatenate([ex.ravel(), ey.ravel(), cx.ravel()])
+    edge[1] = np.concatenate([ey.ravel(), ex.ravel(), cy.ravel()])
+    edge[2], edge[5], edge[6] = 3.0, -1.0, 1e12
+    ref_edge = cpu.trace_closest(edge)
+    check_closest(rt, gpu.trace_closest(edge), ref_edge)
+    occ_edge, _ = cpu.trace_any(edge)
+    assert np.array_equal(gpu.trace_any(edge), occ_edge)
     rays = random_rays(100_000, seed=31, center=(0, 0, 0.5), radius=8.0)
     check_closest(rt, gpu.trace_closest(rays), cpu.trace_closest(rays))
     rays[6] = np.random.default_rng(8).uniform(0.0, 12.0, rays.shape[1]).astype(np.float32)
@@ -182,6 +196,8 @@ def test_two_mesh_scene_with_coplanar_duplicates(rt, ol, sky, n, with_bunny):
     assert np.array_equal(gpu.trace_any(rays), occ)
     gpu.set_option(rt.OPT_LDS_SCENE, 0)
     check_closest(rt, gpu.trace_closest(down), ref)
+    check_closest(rt, gpu.trace_closest(edge), ref_edge)
+    assert np.array_equal(gpu.trace_any(edge), occ_edge)
 
 
 def test_full_4k_primary_batch(rt, ol, sky):
