@@ -468,7 +468,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     std::vector<float4> nodes, tris, normals;
     std::vector<DevMesh> meshes;
     std::vector<DevTree> trees;
-    bool plain_boxes = true;   // every mesh-tree box finite with min <= max
+    bool plain_boxes = true, plain_tree_boxes = true;   // every box of the mesh trees / the object trees finite with min <= max
     int rc;
     {
         size_t nn = 0, nt = 0, nv = 0;
@@ -514,7 +514,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         uint32_t n_mesh = 0;
         for (uint32_t k = 0; k < tr.n_objects; k++) n_mesh += sc->objects[tr.first_object + k].geom_kind == RTAMD_GEOM_MESH ? 1u : 0u;
         dt.deepen = tr.n_nodes >= 257u ? (2u * (uint64_t)n_mesh >= tr.n_objects ? 1u : 2u) : 0u;
-        if ((rc = convert_tree(ctx, tr.nodes, tr.n_nodes, tr.n_objects, "object tree", nodes))) return rc;
+        if ((rc = convert_tree(ctx, tr.nodes, tr.n_nodes, tr.n_objects, "object tree", nodes, &plain_tree_boxes))) return rc;
         trees.push_back(dt);
     }
     std::vector<DevObject> objects;
@@ -739,6 +739,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
     S.plain_boxes = plain_boxes ? 1u : 0u;
+    S.plain_tree_boxes = plain_tree_boxes ? 1u : 0u;
     S.any_box = 0;
     for (const DevObject& o : objects) S.any_box |= (o.xf_kind & XF_BOX) ? 1u : 0u;
     S.features = 0;   // what the objects need besides mesh walks: picks the lean or the general form of the scheduler kernels

@@ -110,6 +110,7 @@ struct DevScene {
     uint32_t mid_bytes;
     uint32_t deepen;          // object-tree walks of the scheduler kernels are repeated with a growing t_max limit (rt_sched.h)
     uint32_t plain_boxes;     // every box of every mesh tree is finite with min <= max: node_passes_plain may stand in for node_passes
+    uint32_t plain_tree_boxes;// the same for the object trees
 };
 
 // ------------------------------------------------------------------------------------------------

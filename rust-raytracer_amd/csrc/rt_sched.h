@@ -22,6 +22,7 @@
 // s_waitcnt vmcnt(0)) in the later FETCH step that first reads it: the ray loads' latency overlaps
 // the traversal phases, and no register holds a pending load.
 #pragma once
+#include <type_traits>
 #include "rt_device.h"
 
 namespace rtamd {
@@ -105,6 +106,11 @@ static constexpr bool NODE_PAIRS = RTAMD_NODE_PAIRS != 0;
 #endif
 // mesh-tree boxes of rays that cannot produce a NaN are tested with plain minima and maxima (node_passes_plain)
 static constexpr bool PLAIN_NODE = RTAMD_PLAIN_NODE != 0;
+#ifndef RTAMD_PLAIN_TNODE
+#define RTAMD_PLAIN_TNODE 1
+#endif
+// the same for the boxes of object trees, chosen per TNODE phase by a wave-uniform flag
+static constexpr bool PLAIN_TNODE = RTAMD_PLAIN_TNODE != 0;
 #ifndef RTAMD_TNODE_PAIRS
 #define RTAMD_TNODE_PAIRS 1
 #endif
@@ -216,7 +222,8 @@ enum : uint32_t {
     F_MLDS = 16u,     // the current mesh is the LDS-resident one (MESH_MIXED only)
     F_PEND = 32u,     // a mesh walk ended and has not been folded into the ray's state yet
     F_FOUND = 64u,    // the current mesh walk accepted a triangle
-    F_GENXF = 128u    // the current object's wrapper chain must be walked op by op
+    F_GENXF = 128u,   // the current object's wrapper chain must be walked op by op
+    F_ODDW = 256u     // the ray can turn a slab product of the current object tree into a NaN: its boxes need node_passes
 };
 // max of two wave-uniform values on the scalar unit
 __device__ __forceinline__ uint32_t smax(uint32_t a, uint32_t b) {
@@ -371,6 +378,12 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
 
     // One node of the current mesh tree (bvh.rs:227-252): visit test, then into the leaf, on to the next
     // node, or along the skip link.  Used by the NODE phase and, for a mesh's root, by the OBJ phase.
+    // Wave-uniform: some lane inside an object tree needs the reference's NaN rules for the tree's boxes (or a tree holds a box
+    // that is not plain).  Set after the OBJ phase, where lanes enter trees, and left standing until that phase runs again.
+    // (not in the general form of the mesh-free kernel, which has no registers to spare for a second copy of the phase, nor for
+    // scenes whose tables fit LDS: at most 64 objects, whose trees, if any, are walked in a few steps)
+    constexpr bool PLAIN_T = PLAIN_TNODE && !Tab::small_scene && (LEAN || MESHLOC != MESH_NONE);
+    bool tree_exact = !PLAIN_T || S.plain_tree_boxes == 0u;
     // (PLAIN_NODE: a ray whose slab products could be NaNs never gets here; its mesh walk is done where it enters the mesh)
     auto node_step = [&]() {
         float4 n0, n1;
@@ -629,6 +642,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           // (a tree of meshes: the lanes that leave for an object are gone for a whole mesh walk, the others are worth waiting
           // for down to 1/4: instanced grid +8 %; a tree of spheres: 3/4, the objects are done in one OBJ step)
           constexpr uint32_t tnode_stay_num = MESHLOC == MESH_NONE ? TNODE_STAY_NUM : TNODE_STAY_NUM_MESH;
+          // The phase exists twice: with the reference's box test (node_passes) while some lane inside an object tree needs its
+          // NaN rules (tree_exact), and with the plain one (node_passes_plain) otherwise: one wave-uniform branch per phase.
+          auto tnode_phase = [&](auto exact_c) {
+          constexpr bool EXACT = decltype(exact_c)::value;
           for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * tnode_stay_num && c > 0; c = wave_count(st == ST_TNODE)) {
             DIAG_STEP(ST_TNODE, c)
             constexpr bool TNODE_PAIRS = TNODE_PAIRS_ON && MESHLOC != MESH_NONE;
@@ -644,8 +661,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 const uint32_t A1 = __float_as_uint(n1.z), B1 = __float_as_uint(n1.w), A2 = __float_as_uint(m1.z), B2 = __float_as_uint(m1.w);
                 const bool leaf1 = (A1 & LEAF_BIT) != 0u, leaf2 = (A2 & LEAF_BIT) != 0u;
                 const uint32_t first1 = A1 & ~LEAF_BIT, first2 = A2 & ~LEAF_BIT;
-                const bool pass1 = node_passes(n0, n1, wpos, winv, sx, sy, sz, tm);
-                const bool pass2 = node_passes(m0, m1, wpos, winv, sx, sy, sz, tm);
+                const bool pass1 = EXACT ? node_passes(n0, n1, wpos, winv, sx, sy, sz, tm) : node_passes_plain(n0, n1, wpos, winv, tm);
+                const bool pass2 = EXACT ? node_passes(m0, m1, wpos, winv, sx, sy, sz, tm) : node_passes_plain(m0, m1, wpos, winv, tm);
                 const bool enter1 = pass1 && leaf1 && first1 < B1;
                 const bool on = !enter1 && (pass1 || leaf1) && t_i + 1u < t_n;
                 const bool enter2 = on && pass2 && leaf2 && first2 < B2;
@@ -666,7 +683,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
                 const bool leaf = (A & LEAF_BIT) != 0u;
                 const uint32_t first = A & ~LEAF_BIT;
-                const bool pass = node_passes(n0, n1, wpos, winv, signbit32(winv.x), signbit32(winv.y), signbit32(winv.z), walk_tmax());
+                const bool pass = EXACT ? node_passes(n0, n1, wpos, winv, signbit32(winv.x), signbit32(winv.y), signbit32(winv.z), walk_tmax())
+                                        : node_passes_plain(n0, n1, wpos, winv, walk_tmax());
                 const bool enter = pass && leaf && first < B;
                 o_cur = enter ? t_first + first : o_cur; o_end = enter ? t_first + B : o_end;
                 t_i = enter ? t_i : ((pass || leaf) ? t_i + 1 : A);
@@ -676,6 +694,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 st = (enter || tree_done) ? ST_OBJ : ST_TNODE;
             }
           }
+          };
+          if (!PLAIN_T || tree_exact) tnode_phase(std::true_type{}); else tnode_phase(std::false_type{});
         }
         if (phase == ST_OBJ) {
           // A lane stays in this phase across objects that end at once: a primitive that is not a mesh, or a mesh
@@ -711,6 +731,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                                 const DevTree tr = tab.tree(it.index);
                                 t_base = tr.node_base; t_n = tr.n_nodes; t_first = tr.first_object; t_i = 0;
                                 if (!S.any_box) winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // bvh.rs:220
+                                if (PLAIN_T) fl = plain_ray(wpos, winv) ? (fl & ~F_ODDW) : (fl | F_ODDW);
                                 if (t_n > 0) { fl |= F_INTREE; st = ST_TNODE; walk_begin(tr.deepen); }
                             }
                         }
@@ -790,6 +811,8 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             }
           }
         }
+        if (PLAIN_T && phase == ST_OBJ && S.plain_tree_boxes != 0u)   // (lanes enter object trees only in the OBJ phase)
+            tree_exact = wave_count((fl & (F_INTREE | F_ODDW)) == (F_INTREE | F_ODDW)) != 0u;
         if (phase == ST_FETCH) {
             DIAG_STEP(ST_FETCH, c_fetch)
             const bool want = st == ST_FETCH;

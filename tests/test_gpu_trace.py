@@ -26,6 +26,30 @@ def random_rays(n, seed, center=(0.0, 0.0, 1.0), radius=9.0, tmax=1e12):
     return np.ascontiguousarray(rays)
 
 
+def rays_in_box_planes(scene, n, seed):
+    """Axis-aligned rays whose origin lies exactly in a plane of a box of the scene's object tree, mixed with such rays from
+    random origins: a slab product of the tree's boxes is 0 x inf = NaN, and the reference's min! / max! rules decide."""
+    words, _, _ = scene.tree(1)
+    box = words[:-1, :6].copy().view(np.float32)            # min xyz, max xyz of every node but the sentinel
+    rng = np.random.default_rng(seed)
+    pick = rng.integers(0, box.shape[0], n)
+    lo, hi = box[pick, 0:3], box[pick, 3:6]
+    o = (lo + (hi - lo) * rng.random((n, 3)).astype(np.float32)).astype(np.float32)
+    plane = rng.integers(0, 3, n)                              # the axis whose plane the origin lies in ...
+    side = rng.random(n) < 0.5
+    o[np.arange(n), plane] = np.where(side, lo[np.arange(n), plane], hi[np.arange(n), plane])
+    along = (plane + 1 + rng.integers(0, 2, n)) % 3            # ... and the axis the ray runs along (another one)
+    d = np.zeros((n, 3), np.float32)
+    d[np.arange(n), along] = np.where(rng.random(n) < 0.5, 1.0, -1.0)
+    back = rng.random(n) < 0.5                                 # half of them start outside the scene and run through it
+    o[back, along[back]] = -d[back, along[back]] * 40.0
+    rays = np.empty((7, n), np.float32)
+    rays[0:3], rays[3:6], rays[6] = o.T, d.T, 1e12
+    loose = np.arange(n) % 4 == 3                              # origins off the planes
+    rays[0:3, loose] += rng.normal(size=(3, int(loose.sum()))).astype(np.float32)
+    return np.ascontiguousarray(rays)
+
+
 def check_closest(rt, got, ref, exact_uv=True):
     ref_obj = ref["obj"].astype(np.int64)
     ref_obj[ref_obj < 0] = rt.MISS
@@ -151,6 +175,26 @@ def test_instanced_grid_scene(rt, ol, sky):
     rays[6] = np.random.default_rng(6).uniform(0.0, 20.0, rays.shape[1]).astype(np.float32)
     ref, _ = cpu.trace_any(rays)
     assert np.array_equal(gpu.trace_any(rays), ref)
+
+
+@pytest.mark.parametrize("kind", ["spheres", "grid"])
+def test_rays_in_the_planes_of_object_tree_boxes(rt, ol, sky, kind):
+    """Object trees of scenes too large for LDS tables (3 000 spheres; 12 x 10 bunny instances): rays that turn slab products
+    of the tree's boxes into NaNs take the reference's box test, the others a plain one; both kinds share waves here."""
+    cam = (64, 64)
+    if kind == "spheres":
+        gpu, cpu = rt.Scene.spheres(n=3000, seed=1, sky=sky, cam=cam), ol.OracleScene.spheres(n=3000, seed=1, sky=sky, cam=cam)
+    else:
+        gpu, cpu = rt.Scene.grid(12, 10, sky=sky, cam=cam), ol.OracleScene.grid(12, 10, sky=sky, cam=cam)
+    gpu.upload(0)
+    rays = rays_in_box_planes(gpu, 40_000, seed=41)
+    mixed = np.ascontiguousarray(np.concatenate([rays, random_rays(40_000, seed=43, center=(0, 0, 1), radius=14.0)], axis=1)[:, np.random.default_rng(2).permutation(80_000)])
+    hits = check_closest(rt, gpu.trace_closest(mixed), cpu.trace_closest(mixed), exact_uv=kind != "spheres")
+    assert hits > 2000
+    mixed[6] = np.random.default_rng(7).uniform(0.0, 30.0, mixed.shape[1]).astype(np.float32)
+    ref, _ = cpu.trace_any(mixed)
+    assert np.array_equal(gpu.trace_any(mixed), ref)
+    assert 0 < ref.sum() < ref.size
 
 
 @pytest.mark.parametrize("n,with_bunny", [(6, True), (70, True), (70, False)])
