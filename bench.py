@@ -175,7 +175,24 @@ def self_launch(n):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # the ranks' stdout is relayed as one JSON line (rank 0's); anything else a library prints there (gloo's connection
+    # messages) goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line_out = None
+    for line in proc.stdout:
+        t = line.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+                line_out = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(line)
+    rc = proc.wait()
+    if line_out is not None:
+        print(line_out, flush=True)
+    return rc
 
 
 def main():
