@@ -582,8 +582,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t c_tnode = wave_count(st == ST_TNODE);
         const uint32_t c_obj = wave_count(st == ST_OBJ);
         const uint32_t c_fetch = wave_count(st == ST_FETCH);
-        const uint32_t c_walk = (PLAIN_NODE && MESHLOC != MESH_NONE) ? wave_count(st == ST_WALK) : 0u;
-        if ((c_tri | c_node | c_tnode | c_obj | c_fetch | c_walk) == 0) break;  // every lane is ST_DONE
+        if ((c_tri | c_node | c_tnode | c_obj | c_fetch) == 0) break;  // every lane is ST_DONE
         // most lanes wins; ties go to the deeper phase (the state codes grow with depth)
         // The mesh phases always get their weight in a small scene (its tables fit LDS): the rays walk few objects
         // in much the same order, so the mesh walks of a wave coincide.  In a scene of thousands of instances the
@@ -596,25 +595,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         key = smax(key, ((c_tnode * VOTE_W_TNODE) << 3) | ST_TNODE);
         key = smax(key, ((c_obj * VOTE_W_OBJ) << 3) | ST_OBJ);
         key = smax(key, ((c_fetch * VOTE_W_FETCH) << 3) | ST_FETCH);
-        const uint32_t phase = c_walk ? (uint32_t)ST_WALK : key & 7u;   // (rare, and gone after one step)
-
-        if (PLAIN_NODE && MESHLOC != MESH_NONE && phase == ST_WALK) {
-            // The boxes of a mesh tree are tested with plain minima and maxima (node_passes_plain), which presumes that no slab
-            // product is a NaN.  A ray for which one can be (a direction component of exactly zero, a non-finite origin, a tree
-            // with a box that is not finite) needs the reference's NaN rules at every box: such rays are rare, and the lane
-            // walks the whole mesh here, by itself, through global memory, as the plain kernels do.  A closest-hit walk also
-            // answers an occlusion query: until its first accepted triangle it is the same walk.
-            if (st == ST_WALK) {
-                const GlobalMem gm{S.nodes + 2 * (size_t)node_off, S.tris + 3 * (size_t)tri_off};
-                float tm = otmax, hu = 0.0f, hv = 0.0f;
-                uint32_t prim = 0u;
-                st = ST_OBJ;
-                if (traverse_mesh<false>(gm, n_n, opos, odir, tm, prim, hu, hv)) {
-                    if (fl & F_ANY) { fl |= F_OCC | F_HAVE; st = ST_FETCH; }
-                    else { otmax = tm; oprim = prim; ou = hu; ov = hv; fl |= F_PEND | F_FOUND; }
-                }
-            }
-        }
+        const uint32_t phase = key & 7u;
 
         if (MESHLOC != MESH_NONE && (phase == ST_TRI || phase == ST_NODE)) {
           // The two mesh phases alternate many times between two steps of any other phase, and they change only a few of
@@ -787,7 +768,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         n_n = ob.n_nodes; n_i = 0; node_off = ob.node_base; tri_off = ob.tri_base;
                         if (MESHLOC == MESH_MIXED) fl = (ob.geom_index == S.lds_mesh) ? (fl | F_MLDS) : (fl & ~F_MLDS);
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
-                        // a ray (or a tree) for which a slab product can be a NaN takes the WALK phase instead of the mesh phases
+                        // a ray (or a tree) for which a slab product can be a NaN walks its mesh alone, after this phase
                         if (PLAIN_NODE && !(S.plain_boxes != 0u && plain_ray(opos, oinv))) st = ST_WALK;
                         else if (n_n > 0) node_step();
                         DIAG_SUB_END(5)
@@ -810,6 +791,24 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 }
             }
           }
+        }
+        if (PLAIN_NODE && MESHLOC != MESH_NONE && phase == ST_OBJ && wave_count(st == ST_WALK) != 0u) {
+            // The boxes of a mesh tree are tested with plain minima and maxima (node_passes_plain), which presumes that no slab
+            // product is a NaN.  A ray for which one can be (a direction component of exactly zero, a non-finite origin, a tree
+            // with a box that is not finite) needs the reference's NaN rules at every box: such rays are rare, the OBJ phase
+            // parks them in ST_WALK, and the lane walks the whole mesh here, by itself, through global memory, as the plain
+            // kernels do, before the next vote.  A closest-hit walk also answers an occlusion query: until its first accepted
+            // triangle it is the same walk.
+            if (st == ST_WALK) {
+                const GlobalMem gm{S.nodes + 2 * (size_t)node_off, S.tris + 3 * (size_t)tri_off};
+                float tm = otmax, hu = 0.0f, hv = 0.0f;
+                uint32_t prim = 0u;
+                st = ST_OBJ;
+                if (traverse_mesh<false>(gm, n_n, opos, odir, tm, prim, hu, hv)) {
+                    if (fl & F_ANY) { fl |= F_OCC | F_HAVE; st = ST_FETCH; }
+                    else { otmax = tm; oprim = prim; ou = hu; ov = hv; fl |= F_PEND | F_FOUND; }
+                }
+            }
         }
         if (PLAIN_T && phase == ST_OBJ && S.plain_tree_boxes != 0u)   // (lanes enter object trees only in the OBJ phase)
             tree_exact = wave_count((fl & (F_INTREE | F_ODDW)) == (F_INTREE | F_ODDW)) != 0u;
