@@ -257,7 +257,9 @@ int rtamd_trace_closest(rtamd_context* ctx, const rtamd_rays* rays, size_t n, co
 int rtamd_trace_any(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out);
 
 /* Same two calls on arrays that already live in this GPU's memory; asynchronous on `stream`
- * (a hipStream_t, NULL = the context's own stream, in which case the call blocks until done). */
+ * (a hipStream_t, NULL = the context's own stream, in which case the call blocks until done).
+ * Every call takes its queue-head word in turn from a ring of 64 words owned by the context: at most 64 such calls of
+ * one context may be in flight at a time (a 65th that overlaps the first shares its head word with it). */
 int rtamd_trace_closest_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, const rtamd_hits* out, void* stream);
 int rtamd_trace_any_device(rtamd_context* ctx, const rtamd_rays* rays, size_t n, uint8_t* out, void* stream);
 
@@ -320,9 +322,20 @@ enum rtamd_option {
                                      for a triangle its ray is parallel to within ~1e-7 rad (triangle.rs:26-28), wherever along the ray
                                      that triangle lies; a walk in passes reports the ray's real nearest hit when it finds one before
                                      its reach includes that triangle (measured: 2 of 16 million grazing rays) */
-    RTAMD_OPT_LEAN_KERNELS = 11   /* 1 (default): a scene that holds only meshes and cuboids (or only spheres and cuboids) under
+    RTAMD_OPT_LEAN_KERNELS = 11,  /* 1 (default): a scene that holds only meshes and cuboids (or only spheres and cuboids) under
                                      Translate / Scale / Rotate chains runs traversal kernels compiled without the code for the other
                                      object kinds and wrappers; 0: always the general kernels.  Same results, bit for bit */
+    RTAMD_OPT_ORDERED_WALK = 12,  /* mesh trees read from global memory, and object trees of meshes / spheres / triangles in scenes too
+                                     large for the LDS tables, walked nearer child first from 64-byte two-child records with a per-lane
+                                     stack in LDS, instead of in the reference's fixed order (src/geom/bvh.rs:227-252): 0 never; 1
+                                     (default) in rtamd_render*; 2 also in the batch entry points.  Same hits (equal t resolved by tree
+                                     order as the reference does), occlusion queries exactly, closest hits with two exceptions: the
+                                     spurious t = 0 hit described under RTAMD_OPT_TREE_DEEPENING, and, in object trees only, two objects
+                                     hit within one rounding step of each other in a different object's scale (the reference compares
+                                     each object's t in that object's own space, so the winner can depend on which is tested first) */
+    RTAMD_OPT_STRICT_ORDER = 13   /* 1: RTAMD_OPT_TREE_DEEPENING = 0 and RTAMD_OPT_ORDERED_WALK = 0 in one call: every entry point visits
+                                     nodes, objects and triangles in the reference's order, with no excepted ray; 0: both back to their
+                                     defaults */
 };
 int rtamd_set_option(rtamd_context* ctx, int option, int64_t value);
 /* Average duration (ms) and launch count of the closest-hit / any-hit trace kernels since the last

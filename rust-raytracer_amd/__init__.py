@@ -27,6 +27,8 @@ OPT_PROFILE, OPT_MAX_PATHS, OPT_LDS_SCENE, OPT_SCHEDULER, OPT_CHUNK, OPT_BLOCKS_
 OPT_DEPTH_FIRST_ROUNDS = 9
 OPT_TREE_DEEPENING = 10
 OPT_LEAN_KERNELS = 11
+OPT_ORDERED_WALK = 12
+OPT_STRICT_ORDER = 13
 
 _f32p = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)

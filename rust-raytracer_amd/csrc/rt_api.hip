@@ -27,6 +27,8 @@ struct rtamd_context {
     bool profile = false;
     bool static_share_set = false;   // RTAMD_OPT_STATIC_SHARE was given: the upload does not pick it
     int deepen = 1;          // object-tree walks in passes of growing reach (rt_sched.h): 0 never, 1 in the render entry points, 2 also in the batch entry points
+    int ordered = 1;         // walks that visit the nearer child first (rt_sched.h): same three values
+    uint32_t ordered_ok = 0; // ORD_MESH / ORD_TREE: the uploaded scene's trees allow them
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
@@ -409,6 +411,14 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
             if (value < 0 || value > 2) return fail(ctx, RTAMD_E_INVALID, "tree deepening mode must be 0, 1 or 2");
             ctx->deepen = (int)value; ctx->S.deepen = ctx->deepen >= 1 ? 1u : 0u;
             return RTAMD_OK;
+        case RTAMD_OPT_ORDERED_WALK:
+            if (value < 0 || value > 2) return fail(ctx, RTAMD_E_INVALID, "ordered walk mode must be 0, 1 or 2");
+            ctx->ordered = (int)value; ctx->S.ordered = ctx->ordered >= 1 ? ctx->ordered_ok : 0u;
+            return RTAMD_OK;
+        case RTAMD_OPT_STRICT_ORDER:
+            ctx->deepen = value != 0 ? 0 : 1; ctx->S.deepen = ctx->deepen >= 1 ? 1u : 0u;
+            ctx->ordered = value != 0 ? 0 : 1; ctx->S.ordered = ctx->ordered >= 1 ? ctx->ordered_ok : 0u;
+            return RTAMD_OK;
         case RTAMD_OPT_SCHEDULER: ctx->cfg.scheduler = value != 0; return RTAMD_OK;
         case RTAMD_OPT_CHUNK:
             if (value < 64 || value > 4096 || (value & (value - 1))) return fail(ctx, RTAMD_E_INVALID, "chunk must be a power of two in [64, 4096]");
@@ -514,9 +524,43 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         uint32_t n_mesh = 0;
         for (uint32_t k = 0; k < tr.n_objects; k++) n_mesh += sc->objects[tr.first_object + k].geom_kind == RTAMD_GEOM_MESH ? 1u : 0u;
         dt.deepen = tr.n_nodes >= 257u ? (2u * (uint64_t)n_mesh >= tr.n_objects ? 1u : 2u) : 0u;
+        // A walk that visits the nearer child first reports what the reference's does as long as a primitive's answer does not
+        // depend on the t_max it is asked with beyond `t <= t_max`; a cuboid that holds the ray's origin answers its far side even
+        // beyond t_max (cuboid.rs:22-28), so a tree with cuboids keeps the reference's order.
+        bool orderable = tr.n_nodes >= 65u;
+        for (uint32_t k = 0; k < tr.n_objects && orderable; k++) {
+            const uint32_t g = sc->objects[tr.first_object + k].geom_kind;
+            orderable = g == RTAMD_GEOM_MESH || g == RTAMD_GEOM_UNIT_SPHERE || g == RTAMD_GEOM_TRIANGLE;
+        }
+        if (orderable) dt.deepen |= TREE_ORDERED;
         if ((rc = convert_tree(ctx, tr.nodes, tr.n_nodes, tr.n_objects, "object tree", nodes, &plain_tree_boxes))) return rc;
         trees.push_back(dt);
     }
+    // Two-child records for the ordered walks (see DevScene::wide): inner node i's record = its children's 32-byte records,
+    // node i + 1 and that node's skip link (or i + 2 behind a leaf).  A tree some inner node of which does not have exactly two
+    // children (no builder of the reference's makes one) is walked in the reference's order only.
+    // (the reference-order part of an ordered walk reads the record behind the node it stands on as well: one record of padding)
+    nodes.push_back(make_float4(0.f, 0.f, 0.f, 0.f)); nodes.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> wide(2 * nodes.size(), make_float4(0.f, 0.f, 0.f, 0.f));
+    auto link_pairs = [&](uint32_t base, uint32_t n) -> bool {
+        auto word = [&](uint32_t i, int w) { uint32_t v; const float4& q = nodes[2 * (size_t)(base + i) + 1]; std::memcpy(&v, w ? &q.w : &q.z, 4); return v; };
+        auto skip_of = [&](uint32_t i) { const uint32_t a = word(i, 0); return (a & LEAF_BIT) ? i + 1u : a; };
+        for (uint32_t i = 0; i < n; i++) {
+            if (word(i, 0) & LEAF_BIT) continue;
+            const uint32_t l = i + 1u;
+            if (l >= n) return false;
+            const uint32_t r = skip_of(l);
+            if (r <= l || r >= n || skip_of(r) != skip_of(i)) return false;
+            float4* rec = &wide[4 * (size_t)(base + i)];
+            rec[0] = nodes[2 * (size_t)(base + l)]; rec[1] = nodes[2 * (size_t)(base + l) + 1];
+            rec[2] = nodes[2 * (size_t)(base + r)]; rec[3] = nodes[2 * (size_t)(base + r) + 1];
+        }
+        return true;
+    };
+    bool pairs_meshes = true;
+    for (const DevMesh& m : meshes) pairs_meshes = link_pairs(m.node_base, m.n_nodes) && pairs_meshes;
+    for (DevTree& t : trees)
+        if (!link_pairs(t.node_base, t.n_nodes)) t.deepen &= ~TREE_ORDERED;
     std::vector<DevObject> objects;
     for (uint32_t o = 0; o < sc->n_objects; o++) {
         const rtamd_object& ob = sc->objects[o];
@@ -703,6 +747,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
 
     DevScene S{};
     if ((rc = upload_vec(ctx, nodes, &S.nodes))) return rc;
+    if ((rc = upload_vec(ctx, wide, &S.wide))) return rc;
     if ((rc = upload_vec(ctx, tris, &S.tris))) return rc;
     if ((rc = upload_vec(ctx, normals, &S.normals))) return rc;
     if ((rc = upload_vec(ctx, meshes, &S.meshes))) return rc;
@@ -781,6 +826,8 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         ctx->cfg.static_share = big_tree ? 3 : 6;
     }
     S.deepen = ctx->deepen >= 1 ? 1u : 0u;   // what the render entry points pass to their kernels; the batch entry points decide per call
+    ctx->ordered_ok = (pairs_meshes ? ORD_MESH : 0u) | ORD_TREE;   // (object trees carry their own flag, DevTree::deepen)
+    S.ordered = ctx->ordered >= 1 ? ctx->ordered_ok : 0u;
     ctx->S = S;
     ctx->have_scene = true;
     return RTAMD_OK;
@@ -794,6 +841,7 @@ namespace {
 DevScene batch_scene(const rtamd_context* ctx) {
     DevScene S = ctx->S;
     S.deepen = ctx->deepen >= 2 ? 1u : 0u;
+    S.ordered = ctx->ordered >= 2 ? ctx->ordered_ok : 0u;
     return S;
 }
 }  // namespace

@@ -28,7 +28,10 @@ static constexpr uint32_t LEAF_BIT = 0x80000000u;
 static constexpr uint32_t MISS = 0xFFFFFFFFu;
 
 struct DevMesh { uint32_t node_base, n_nodes, tri_base, normal_base; };   // n_nodes excludes the sentinel
-struct DevTree { uint32_t node_base, n_nodes, first_object, deepen; };   // deepen: walk in passes of growing reach (rt_sched.h)
+// deepen: bits 0-1 walk in passes of growing reach (rt_sched.h; 1 a tree of meshes, 2 a tree of cheap objects), bit 2 (TREE_ORDERED)
+// the tree may be walked nearer child first (every object a mesh, a sphere or a triangle, the tree strictly binary)
+struct DevTree { uint32_t node_base, n_nodes, first_object, deepen; };
+static constexpr uint32_t TREE_DEEPEN_MASK = 3u, TREE_ORDERED = 4u;
 struct DevCuboid { float center[3], extent[3], inv_extent[3]; float pad[3]; };
 struct DevTriangle { float a[3], b[3], c[3]; float pad[3]; };
 struct DevOp { uint32_t kind; float v[9]; uint32_t pad[2]; };
@@ -111,7 +114,14 @@ struct DevScene {
     uint32_t deepen;          // object-tree walks of the scheduler kernels are repeated with a growing t_max limit (rt_sched.h)
     uint32_t plain_boxes;     // every box of every mesh tree is finite with min <= max: node_passes_plain may stand in for node_passes
     uint32_t plain_tree_boxes;// the same for the object trees
+    // Two-child records of every tree, for walks that visit the nearer child first: record i of a tree (4 x float4 at
+    // wide[4 * (node_base + i)], 64 bytes, meaningful for inner nodes only) holds the 32-byte records of node i's two
+    // children side by side, left (node i + 1) first; the right child's index is the left child's skip link, or i + 2
+    // behind a left leaf.
+    const float4* wide;
+    uint32_t ordered;         // ORD_MESH: mesh trees in global memory are walked nearer child first; ORD_TREE: object trees flagged TREE_ORDERED too
 };
+static constexpr uint32_t ORD_MESH = 1u, ORD_TREE = 2u;
 
 // ------------------------------------------------------------------------------------------------
 // Exact-order float3 helpers (src/math/vec3d.rs:115-126,181-287).
@@ -216,6 +226,38 @@ __device__ __forceinline__ bool node_passes_plain(float4 n0, float4 n1, f3 pos, 
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(fx), "v"(fy), "v"(fz));
     return (t0 < t1) && (t0 <= t_max + 0.01f) && (t1 >= -0.01f);
 }
+// Both tests again, also handing out the entry parameter t0 of the box: what an ordered walk sorts the two children of a
+// node by, and what it keeps with a postponed child so that the child is dropped without a read once the ray's t_max has
+// shrunk below it (`t0 <= t_max + 0.01` is the only part of the visit test that depends on t_max).
+template <bool EXACT>
+__device__ __forceinline__ bool node_test(float4 n0, float4 n1, f3 pos, f3 inv, float t_max, float& t0_out) {
+    float ax = (n0.x - pos.x) * inv.x, ay = (n0.y - pos.y) * inv.y, az = (n0.z - pos.z) * inv.z;
+    float bx = (n0.w - pos.x) * inv.x, by = (n1.x - pos.y) * inv.y, bz = (n1.y - pos.z) * inv.z;
+    float t0, t1;
+    if (EXACT) {
+        const bool ngx = (__float_as_uint(inv.x) >> 31) != 0u, ngy = (__float_as_uint(inv.y) >> 31) != 0u, ngz = (__float_as_uint(inv.z) >> 31) != 0u;
+        float a0 = ngx ? bx : ax, b0 = ngx ? ax : bx;
+        float a1 = ngy ? by : ay, b1 = ngy ? ay : by;
+        float a2 = ngz ? bz : az, b2 = ngz ? az : bz;
+        float m = a1 > a2 ? a1 : a2;
+        t0 = a0 > m ? a0 : m;
+        float w = b1 < b2 ? b1 : b2;
+        t1 = b0 < w ? b0 : w;
+    } else {
+        float nx, ny, nz, fx, fy, fz;
+        asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(ax), "v"(bx));
+        asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ay), "v"(by));
+        asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(az), "v"(bz));
+        asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(ax), "v"(bx));
+        asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ay), "v"(by));
+        asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(az), "v"(bz));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(nx), "v"(ny), "v"(nz));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(fx), "v"(fy), "v"(fz));
+    }
+    t0_out = t0;
+    return (t0 < t1) && (t0 <= t_max + 0.01f) && (t1 >= -0.01f);
+}
+
 // Whether node_passes_plain is licensed for a ray: origin finite, reciprocal direction a normal number (a denormal one
 // could be flushed to zero and meet an overflowed difference).  Class masks of v_cmp_class_f32: bit 0 sNaN, 1 qNaN, 2 -inf,
 // 3 -normal, 4 -denormal, 5 -0, 6 +0, 7 +denormal, 8 +normal, 9 +inf.

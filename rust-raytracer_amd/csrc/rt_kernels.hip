@@ -220,16 +220,18 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
         if (blockIdx.x >= (n + bs - 1u) / bs) return;
     }
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
-    __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][COOP_WORDS / 2];
+    __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][MESHLOC == MESH_NONE ? 1 : COOP_WORDS / 2];   // (the triangle phase's)
+    __shared__ unsigned long long ord_stack[TRACE_BLOCK / 64][sched_stack_depth(MESHLOC) ? 64 * sched_stack_depth(MESHLOC) : 1];
     LdsMesh lds;
     LdsTab ltab;
     MidTab mtab;
     stage_scene<MESHLOC, TABKIND>(S, lds, ltab, mtab);
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
     lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
-    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, work_head, n, chunk, stage, coop);
-    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, work_head, n, chunk, stage, coop);
-    else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage, coop);
+    lds_u32* ostack = (lds_u32*)ord_stack[threadIdx.x >> 6];
+    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, work_head, n, chunk, stage, coop, ostack);
+    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, work_head, n, chunk, stage, coop, ostack);
+    else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage, coop, ostack);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -665,18 +667,20 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     }
     const uint32_t chunk = chunk_hint;
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
-    __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][COOP_WORDS / 2];
+    __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][MESHLOC == MESH_NONE ? 1 : COOP_WORDS / 2];   // (the triangle phase's)
+    __shared__ unsigned long long ord_stack[TRACE_BLOCK / 64][sched_stack_depth(MESHLOC) ? 64 * sched_stack_depth(MESHLOC) : 1];
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
     lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
+    lds_u32* ostack = (lds_u32*)ord_stack[threadIdx.x >> 6];
     LdsMesh lds;
     LdsTab ltab;
     MidTab mtab;
     stage_scene<MESHLOC, TABKIND>(S, lds, ltab, mtab);
     WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.p_ray, W.set[0].a_ray, W.set[1].a_ray, W.set[0].a_vidx, W.set[1].a_vidx, W.h_rec, W.p_rec,
               W.set[0].vis, W.set[1].vis, W.cap, W.any_cap, n_q, n_closest, n_closest + n_a0};
-    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
-    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
-    else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop);
+    if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop, ostack);
+    else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, &W.counts[head_idx], n, chunk, stage, coop, ostack);
+    else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop, ostack);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -223,8 +223,13 @@ enum : uint32_t {
     F_PEND = 32u,     // a mesh walk ended and has not been folded into the ray's state yet
     F_FOUND = 64u,    // the current mesh walk accepted a triangle
     F_GENXF = 128u,   // the current object's wrapper chain must be walked op by op
-    F_ODDW = 256u     // the ray can turn a slab product of the current object tree into a NaN: its boxes need node_passes
+    F_ODDW = 256u,    // the ray can turn a slab product of the current object tree into a NaN: its boxes need node_passes
+    F_MRANGE = 512u,  // ordered mesh walk: a subtree is being walked in the reference's order (the stack was full)
+    F_TORD = 1024u,   // the current object tree is walked nearer child first
+    F_TRANGE = 2048u  // ordered object-tree walk: a subtree is being walked in the reference's order
 };
+// Ordered walks keep the number of postponed children in the flag word: bits 16-19 the mesh walk's, 20-23 the object tree's.
+static constexpr uint32_t SPM_SHIFT = 16u, SPT_SHIFT = 20u, SP_MASK = 15u;
 // max of two wave-uniform values on the scalar unit
 __device__ __forceinline__ uint32_t smax(uint32_t a, uint32_t b) {
     uint32_t r;
@@ -266,15 +271,123 @@ __device__ __forceinline__ float lane_pull(uint32_t src_lane, float v) { return 
 static constexpr uint32_t COOP_WORDS = 64 + 128 + 192;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
+// ------------------------------------------------------------------------------------------------
+// Walks that visit the nearer child first.  The reference's walk (bvh.rs:227-252) takes the children of a node in the
+// order the builder left them; the closest hit it reports does not depend on that order except through the running
+// t_max it culls with and through ties: `t <= t_max` lets a later primitive replace an earlier one at the same t, so
+// among equal t the last in tree order wins.  A walk in any order that tests every box and primitive with the same
+// arithmetic, culls with its own running t_max and resolves equal t by tree order (tri_phase) finds the same hit, because
+// the boxes over the nearest hit are entered no later than its t.  One case differs: a triangle the ray is parallel to
+// answers t = 0 (triangle.rs:26-28, accepted by mesh.rs:130) wherever along the ray it lies; the reference reports it
+// if it reaches the triangle's leaf before a nearer real hit has shrunk t_max below the leaf's box, a nearest-first walk
+// usually does not.  Occlusion queries are exact in any order (constant t_max).
+//
+// Every lane has a short stack of postponed children in LDS: entry e of lane l at words 2 * (64 e + l) of the wave's
+// area: {LEAF_BIT | node index, entry parameter t0 of the child's box}.  A popped child whose t0 has fallen behind the
+// ray's t_max is dropped without a read.  When both children are hit and the stack is full, the node's whole subtree is
+// walked in the reference's order instead (skip links need no stack), then the walk pops on.
+//   ni: NI_ROOT the tree's root is to be tested; LEAF_BIT | i: leaf i, taken from the stack, is to be entered; else inner node
+//       i, whose two children are tested now (one 64-byte record).  In range mode: the node the reference-order walk
+//       stands on, nend its end; that walk tests two consecutive nodes per step, as node_step2 does.
+//   Every case reads 64 bytes at one address, so lanes in different cases share the step's one memory round trip.
+//   out: leaf (first, end: the caller runs the leaf, then ordered_leaf_done), done (nothing left).
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t NI_ROOT = 0x7FFFFFFFu;
+// The next postponed child that still passes `t0 <= t_max + 0.01` (the one part of the visit test that depends on t_max).
+__device__ __forceinline__ bool ordered_pop(uint32_t& ni, uint32_t& sp, lds_u32* slot0, const float tmax) {
+    while (sp > 0u) {
+        sp--;
+        const unsigned long long e = *(lds_u64*)(slot0 + 128u * sp);
+        if (__uint_as_float((uint32_t)(e >> 32)) <= tmax + 0.01f) { ni = (uint32_t)e; return true; }
+    }
+    return false;
+}
+template <bool EXACT>
+__device__ __forceinline__ void ordered_step(const float4* nodes, const float4* wide, const f3 pos, const f3 inv, const float tmax, uint32_t& ni, uint32_t& nend,
+                                             uint32_t& sp, const uint32_t sp_cap, bool& range, lds_u32* slot0 /* word 0 of this lane's entry 0 */, bool& leaf,
+                                             uint32_t& first, uint32_t& end, bool& done) {
+    leaf = false; done = false;
+    const bool at_root = !range && ni == NI_ROOT;
+    const bool popped_leaf = !range && !at_root && (ni & LEAF_BIT) != 0u;
+    const uint32_t idx = ni & ~LEAF_BIT;
+    const float4* rec = (range || popped_leaf) ? nodes + 2 * (size_t)idx : (at_root ? nodes : wide + 4 * (size_t)idx);
+    const float4 a0 = rec[0], a1 = rec[1], b0 = rec[2], b1 = rec[3];
+    const uint32_t A1 = __float_as_uint(a1.z), B1 = __float_as_uint(a1.w), A2 = __float_as_uint(b1.z), B2 = __float_as_uint(b1.w);
+    const bool leaf1 = (A1 & LEAF_BIT) != 0u, leaf2 = (A2 & LEAF_BIT) != 0u;
+    const uint32_t first1 = A1 & ~LEAF_BIT, first2 = A2 & ~LEAF_BIT;
+    float t01, t02;
+    const bool pass1 = node_test<EXACT>(a0, a1, pos, inv, tmax, t01);
+    const bool pass2 = node_test<EXACT>(b0, b1, pos, inv, tmax, t02);
+    if (range) {   // nodes ni and ni + 1 of the reference-order walk of [ni, nend)
+        const bool enter1 = pass1 && leaf1 && first1 < B1;
+        const bool on = !enter1 && (pass1 || leaf1) && ni + 1u < nend;
+        const bool enter2 = on && pass2 && leaf2 && first2 < B2;
+        const uint32_t next1 = (pass1 || leaf1) ? ni + 1u : A1;
+        const uint32_t next2 = enter2 ? ni + 1u : ((pass2 || leaf2) ? ni + 2u : A2);
+        ni = enter1 ? ni : (on ? next2 : next1);
+        if (enter1 || enter2) { leaf = true; first = enter1 ? first1 : first2; end = enter1 ? B1 : B2; return; }
+        if (ni >= nend) { range = false; done = !ordered_pop(ni, sp, slot0, tmax); }
+        return;
+    }
+    if (popped_leaf) { leaf = true; first = first1; end = B1; return; }   // (its box passed when it was postponed and when it was popped)
+    if (at_root) {
+        if (pass1 && leaf1 && first1 < B1) { leaf = true; first = first1; end = B1; return; }
+        if (!pass1 || leaf1) { done = true; return; }
+        ni = 0u;   // the root's two-child record
+        return;
+    }
+    // a0, a1: the left child (node idx + 1); b0, b1: the right one (the left child's skip link, or idx + 2 behind a left leaf)
+    const uint32_t l_idx = idx + 1u, r_idx = leaf1 ? idx + 2u : A1;
+    // (an empty leaf is visited and left at once: nothing to do there)
+    const bool hit_l = pass1 && (!leaf1 || first1 < B1), hit_r = pass2 && (!leaf2 || first2 < B2);
+    const bool both = hit_l && hit_r;
+    if (both && sp >= sp_cap) {   // no room to postpone a child: this node's subtree in the reference's order
+        range = true; ni = l_idx; nend = leaf2 ? r_idx + 1u : A2;
+        return;
+    }
+    const bool right_first = both ? t02 < t01 : hit_r;   // equal: the left child, as the reference
+    if (both) {
+        const uint32_t w0 = right_first ? ((leaf1 ? LEAF_BIT : 0u) | l_idx) : ((leaf2 ? LEAF_BIT : 0u) | r_idx);
+        *(lds_u64*)(slot0 + 128u * sp) = ((unsigned long long)__float_as_uint(right_first ? t01 : t02) << 32) | w0;
+        sp++;
+    }
+    if (hit_l || hit_r) {
+        const bool n_leaf = right_first ? leaf2 : leaf1;
+        leaf = n_leaf; first = right_first ? first2 : first1; end = right_first ? B2 : B1;
+        ni = right_first ? r_idx : l_idx;
+    } else {
+        done = !ordered_pop(ni, sp, slot0, tmax);
+    }
+}
+// The leaf handed out by ordered_step is done (tmax: the ray's t_max now).  True: nothing is left of the walk.
+__device__ __forceinline__ bool ordered_leaf_done(uint32_t& ni, const uint32_t nend, uint32_t& sp, bool& range, lds_u32* slot0, const float tmax) {
+    if (range) {
+        ni++;
+        if (ni < nend) return false;
+        range = false;
+    }
+    return !ordered_pop(ni, sp, slot0, tmax);
+}
+
 // The lean form of a scheduler kernel serves scenes that hold nothing but what most scenes hold: meshes and cuboids under
 // inline wrapper chains (or, without meshes, spheres and cuboids).  Any other scene runs the general form.
 __host__ __device__ constexpr uint32_t sched_features(int meshloc, bool lean) {
     return !lean ? FEAT_ALL : (meshloc == MESH_NONE ? (FEAT_SPHERE | FEAT_CUBOID) : FEAT_CUBOID);
 }
+// Entries per lane of the ordered walks' stack (sched_stack_depth(MESHLOC) x 512 bytes per wave), 0: no ordered walks in this
+// instance.  Mesh trees in global memory: what two 512-thread blocks per CU leave of the 160 KB; scenes without meshes run
+// three blocks per CU.  Instances that stage a mesh in LDS have no room (and their tree needs none: it is small).
+__host__ __device__ constexpr uint32_t sched_stack_depth(int meshloc) { return meshloc == MESH_GLOBAL ? 10u : (meshloc == MESH_NONE ? 7u : 0u); }
 template <int MESHLOC, bool LEAN, class Tab, class IO>
 __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
                                                 const uint32_t n_items, const uint32_t chunk_and_share, lds_u32* stage /* this wave's STAGE_WORDS */,
-                                                lds_u32* coop /* this wave's COOP_WORDS */) {
+                                                lds_u32* coop /* this wave's COOP_WORDS */, lds_u32* ostack /* this wave's 128 * sched_stack_depth(MESHLOC) words */) {
+    constexpr uint32_t SD = sched_stack_depth(MESHLOC);
+    // mesh trees in global memory / object trees of scenes whose tables do not fit LDS can be walked nearer child first
+    constexpr bool ORD_M = SD > 0u && MESHLOC == MESH_GLOBAL, ORD_T = SD > 0u && !Tab::small_scene;
+    const bool ord_m = ORD_M && (S.ordered & ORD_MESH) != 0u, ord_t = ORD_T && (S.ordered & ORD_TREE) != 0u;   // wave-uniform
+    // the object tree leaves two entries to the mesh walks inside it
+    constexpr uint32_t SD_T = ORD_M ? (SD > 2u ? SD - 2u : 0u) : SD;
     const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = (chunk_and_share >> 16) & 0xFu;
     const uint32_t lane = lane_id();
     constexpr uint32_t FEAT = sched_features(MESHLOC, LEAN);
@@ -349,17 +462,20 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     // first pass reaches 8 object spacings into the tree's box, each further one four times as far.
     auto walk_begin = [&](const uint32_t tree_deepen) {
         t_lim = __builtin_inff();
-        if (DEEPEN && S.deepen && tree_deepen) {
+        if (DEEPEN && S.deepen && (tree_deepen & TREE_DEEPEN_MASK)) {
             float t_en, t_ex;
             const float cell = tree_span(t_en, t_ex);
             const float s0 = t_en > 0.0f ? t_en : 0.0f;
             // Trees of mesh objects (tree_deepen = 1): every object a pass leaves out is a whole mesh walk.  Trees of cheap
             // objects (spheres, cuboids; 2): an object costs less than a second descent from the root, only the long rays
             // are limited, and later.
-            const float start = s0 + (tree_deepen == 1u ? (float)RTAMD_DEEP_START : (float)RTAMD_DEEP_START_CHEAP) * cell;
-            const float span = (tree_deepen == 1u ? (float)RTAMD_DEEP_SPAN : (float)RTAMD_DEEP_SPAN_CHEAP) * cell;
+            const bool of_meshes = (tree_deepen & TREE_DEEPEN_MASK) == 1u;
+            const float start = s0 + (of_meshes ? (float)RTAMD_DEEP_START : (float)RTAMD_DEEP_START_CHEAP) * cell;
+            const float span = (of_meshes ? (float)RTAMD_DEEP_SPAN : (float)RTAMD_DEEP_SPAN_CHEAP) * cell;
             // (every comparison is false on NaN: such rays walk once, unlimited)
-            if (fabsf(t_en) < 2048.0f && fabsf(t_ex) < 2048.0f && t_ex - s0 > span && start < wtmax) t_lim = start;
+            // (a limit that does not lie beyond the entry point -- a degenerate root box, or a spacing below the resolution of
+            // the entry parameter -- could never grow: such a walk is not limited)
+            if (fabsf(t_en) < 2048.0f && fabsf(t_ex) < 2048.0f && t_ex - s0 > span && start < wtmax && start > s0) t_lim = start;
         }
     };
     // The walk has ended.  True: it found nothing within its limit and starts over with a wider one.
@@ -369,7 +485,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         (void)tree_span(t_en, t_ex);
         const float s0 = t_en > 0.0f ? t_en : 0.0f;
         const float wider = s0 + (t_lim - s0) * (float)RTAMD_DEEP_GROW;
-        t_lim = wider < t_ex + 0.02f ? wider : __builtin_inff();
+        t_lim = (wider > t_lim && wider < t_ex + 0.02f) ? wider : __builtin_inff();   // (a limit that cannot grow is dropped)
         t_i = 0;
         return true;
     };
@@ -443,6 +559,20 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const bool mesh_done = !enter && n_i >= n_n;
         fl |= mesh_done ? F_PEND : 0u;
         st = enter ? ST_TRI : (mesh_done ? ST_OBJ : ST_NODE);
+    };
+
+    // One step of the ordered walk of the current mesh tree (ordered_step): n_n doubles as the end of a subtree walked in
+    // the reference's order.
+    auto node_step_ord = [&]() {
+        uint32_t spm = (fl >> SPM_SHIFT) & SP_MASK;
+        const uint32_t spt = ORD_T ? (fl >> SPT_SHIFT) & SP_MASK : 0u;
+        bool range = (fl & F_MRANGE) != 0u, leaf, done;
+        uint32_t first = 0u, end = 0u;
+        ordered_step<!PLAIN_NODE>(S.nodes + 2 * (size_t)node_off, S.wide + 4 * (size_t)node_off, opos, oinv, otmax, n_i, n_n, spm, SD - spt, range,
+                                  ostack + 2u * lane + 128u * spt, leaf, first, end, done);
+        fl = (fl & ~(F_MRANGE | (SP_MASK << SPM_SHIFT))) | (range ? F_MRANGE : 0u) | (spm << SPM_SHIFT) | (done ? F_PEND : 0u);
+        k_cur = leaf ? first : k_cur; k_end = leaf ? end : k_end;
+        st = leaf ? ST_TRI : (done ? ST_OBJ : ST_NODE);
     };
 
     DIAG_DECL
@@ -554,14 +684,27 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 const unsigned long long res = slot[lane];
                 const bool found = res != ~0ull;
                 const bool is_any = (fl & F_ANY) != 0u;
-                const bool hit_c = found && !is_any, hit_a = found && is_any;
+                const bool hit_a = found && is_any;
+                bool hit_c = found && !is_any;
+                // (an ordered walk can come upon a triangle at the t of the hit it holds after a later one in tree order: among
+                // equal t the reference keeps the last in tree order, mesh.rs:130)
+                if (ORD_M && ord_m && hit_c && (fl & F_FOUND) && __uint_as_float(pay[lane]) == otmax && 0xFFFFFFFFu - (uint32_t)res < oprim) hit_c = false;
                 if (hit_c) {
                     otmax = __uint_as_float(pay[lane]); ou = __uint_as_float(pay[64 + lane]); ov = __uint_as_float(pay[128 + lane]);
                     oprim = 0xFFFFFFFFu - (uint32_t)res;
                 }
                 k_cur = k_end;
-                n_i++;
-                const bool mesh_done = n_i >= n_n;
+                bool mesh_done;
+                if (ORD_M && ord_m) {
+                    bool range = (fl & F_MRANGE) != 0u;
+                    uint32_t spm = (fl >> SPM_SHIFT) & SP_MASK;
+                    const uint32_t spt = ORD_T ? (fl >> SPT_SHIFT) & SP_MASK : 0u;
+                    mesh_done = hit_a || ordered_leaf_done(n_i, n_n, spm, range, ostack + 2u * lane + 128u * spt, otmax);
+                    fl = (fl & ~(F_MRANGE | (SP_MASK << SPM_SHIFT))) | (range ? F_MRANGE : 0u) | (spm << SPM_SHIFT);
+                } else {
+                    n_i++;
+                    mesh_done = n_i >= n_n;
+                }
                 fl |= (hit_c ? F_FOUND : 0u) | (hit_a ? (F_OCC | F_HAVE) : 0u) | ((mesh_done && !hit_a) ? F_PEND : 0u);
                 st = hit_a ? ST_FETCH : (mesh_done ? ST_OBJ : ST_NODE);
             }
@@ -570,7 +713,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     auto node_phase = [&](const uint32_t c_first) {
           for (uint32_t c = c_first; c * NODE_STAY_DEN >= c_first * NODE_STAY_NUM && (NODE_STAY_NUM > 0u || c > 0u); c = wave_count(st == ST_NODE)) {
             DIAG_STEP(ST_NODE, c)
-            if (st == ST_NODE) { if (NODE_PAIRS && (MESHLOC == MESH_GLOBAL || MESHLOC == MESH_MIXED)) node_step2(); else node_step(); }
+            if (st == ST_NODE) {
+                if (ORD_M && ord_m) node_step_ord();
+                else if (NODE_PAIRS && (MESHLOC == MESH_GLOBAL || MESHLOC == MESH_MIXED)) node_step2();
+                else node_step();
+            }
           }
     };
     for (;;) {
@@ -630,7 +777,19 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           for (uint32_t c = c_tnode; c * STAY_DEN >= c_tnode * tnode_stay_num && c > 0; c = wave_count(st == ST_TNODE)) {
             DIAG_STEP(ST_TNODE, c)
             constexpr bool TNODE_PAIRS = TNODE_PAIRS_ON && MESHLOC != MESH_NONE;
-            if (TNODE_PAIRS && st == ST_TNODE) {
+            if (ORD_T && st == ST_TNODE && (fl & F_TORD)) {
+                // nearer child first (ordered_step): t_n doubles as the end of a subtree walked in the reference's order
+                uint32_t spt = (fl >> SPT_SHIFT) & SP_MASK;
+                bool range = (fl & F_TRANGE) != 0u, leaf, done;
+                uint32_t first = 0u, end = 0u;
+                ordered_step<EXACT>(S.nodes + 2 * (size_t)t_base, S.wide + 4 * (size_t)t_base, wpos, winv, wtmax, t_i, t_n, spt, SD_T, range, ostack + 2u * lane,
+                                    leaf, first, end, done);
+                fl = (fl & ~(F_TRANGE | (SP_MASK << SPT_SHIFT))) | (range ? F_TRANGE : 0u) | (spt << SPT_SHIFT);
+                o_cur = leaf ? t_first + first : o_cur; o_end = leaf ? t_first + end : o_end;
+                fl &= done ? ~(F_INTREE | F_TORD) : ~0u;
+                st = (leaf || done) ? ST_OBJ : ST_TNODE;
+            }
+            if (TNODE_PAIRS && st == ST_TNODE && !(ORD_T && (fl & F_TORD))) {
                 // two nodes per step, as node_step2 does for a mesh tree in global memory: the object tree's nodes are read
                 // through L2, and the node behind the current one comes with the same round trip
                 const uint32_t i2 = t_i + 1u < t_n ? t_i + 1u : t_i;
@@ -658,7 +817,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 fl &= tree_done ? ~F_INTREE : ~0u;
                 st = (enter || tree_done) ? ST_OBJ : ST_TNODE;
             }
-            if (!TNODE_PAIRS && st == ST_TNODE) {
+            if (!TNODE_PAIRS && st == ST_TNODE && !(ORD_T && (fl & F_TORD))) {
                 const float4* np = S.nodes + 2 * ((size_t)t_base + t_i);
                 float4 n0 = np[0], n1 = np[1];
                 const uint32_t A = __float_as_uint(n1.z), B = __float_as_uint(n1.w);
@@ -691,14 +850,25 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             if (st == ST_OBJ) {
                 // (1) fold a finished mesh walk into the ray's closest hit (bvh.rs:262-264, transform.rs:107)
                 if (MESHLOC != MESH_NONE && (fl & (F_PEND | F_FOUND)) == (F_PEND | F_FOUND)) {
-                    best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
-                    wtmax = otmax * oscale;
-                    if (GENERIC_XF && (fl & F_GENXF)) { const ObjHead ob = tab.object(oi); wtmax = ops_t_out(tab, ob.op_first, ob.op_count, otmax); }
+                    float t_out = otmax * oscale;
+                    if (GENERIC_XF && (fl & F_GENXF)) { const ObjHead ob = tab.object(oi); t_out = ops_t_out(tab, ob.op_first, ob.op_count, otmax); }
+                    // (an ordered tree walk can reach an object after one that follows it in tree order: at the same t the
+                    // reference keeps the later one, aggregate.rs:28-31)
+                    if (!(ORD_T && (fl & F_TORD) && best.obj != MISS && t_out == wtmax && oi < best.obj)) {
+                        best.obj = oi; best.prim = oprim; best.t_local = otmax; best.u = ou; best.v = ov;
+                        wtmax = t_out;
+                    }
                 }
                 fl &= ~(F_PEND | F_FOUND);
                 // (2) where does the next object come from?
                 if (o_cur == o_end) {
-                    if (fl & F_INTREE) {  // leaf of the object tree finished: i += 1
+                    if (ORD_T && (fl & F_TORD)) {   // leaf of an ordered walk finished
+                        bool range = (fl & F_TRANGE) != 0u;
+                        uint32_t spt = (fl >> SPT_SHIFT) & SP_MASK;
+                        const bool tree_done = ordered_leaf_done(t_i, t_n, spt, range, ostack + 2u * lane, wtmax);
+                        fl = (fl & ~(F_TRANGE | (SP_MASK << SPT_SHIFT))) | (range ? F_TRANGE : 0u) | (spt << SPT_SHIFT);
+                        if (tree_done) fl &= ~(F_INTREE | F_TORD); else st = ST_TNODE;
+                    } else if (fl & F_INTREE) {  // leaf of the object tree finished: i += 1
                         t_i++;
                         if (t_i >= t_n && !walk_again()) fl &= ~F_INTREE; else st = ST_TNODE;
                     }
@@ -713,7 +883,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                                 t_base = tr.node_base; t_n = tr.n_nodes; t_first = tr.first_object; t_i = 0;
                                 if (!S.any_box) winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // bvh.rs:220
                                 if (PLAIN_T) fl = plain_ray(wpos, winv) ? (fl & ~F_ODDW) : (fl | F_ODDW);
-                                if (t_n > 0) { fl |= F_INTREE; st = ST_TNODE; walk_begin(tr.deepen); }
+                                if (t_n > 0) {
+                                    fl |= F_INTREE; st = ST_TNODE;
+                                    if (ORD_T && ord_t && (tr.deepen & TREE_ORDERED)) {
+                                        fl = (fl & ~(F_TRANGE | (SP_MASK << SPT_SHIFT))) | F_TORD;
+                                        t_i = NI_ROOT; t_lim = __builtin_inff();
+                                    } else walk_begin(tr.deepen);
+                                }
                             }
                         }
                     }
@@ -770,7 +946,15 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         oinv = mk(1.0f / odir.x, 1.0f / odir.y, 1.0f / odir.z);  // bvh.rs:220
                         // a ray (or a tree) for which a slab product can be a NaN walks its mesh alone, after this phase
                         if (PLAIN_NODE && !(S.plain_boxes != 0u && plain_ray(opos, oinv))) st = ST_WALK;
-                        else if (n_n > 0) node_step();
+                        else if (n_n > 0) {
+                            node_step();   // the root's own box
+                            if (ORD_M && ord_m) {   // behind a root that is an inner node the walk goes on from its two-child record
+                                // (occlusion queries too: their t_max is constant, but what occludes a shadow ray tends to lie near
+                                // its origin -- leaving them in the reference's order costs 4-15 % of a frame)
+                                fl &= ~(F_MRANGE | (SP_MASK << SPM_SHIFT));
+                                n_i = st == ST_NODE ? 0u : n_i;
+                            }
+                        }
                         DIAG_SUB_END(5)
                     } else {
                         float t = 0.0f;
@@ -781,9 +965,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                         } else {
                             float u = 0.f, v = 0.f;
                             hit = primitive_closest<FEAT>(S, tab, ob, opos, odir, otmax, t, u, v);
-                            if (hit) {
+                            const float t_out = !hit ? 0.0f : ((GENERIC_XF && (fl & F_GENXF)) ? ops_t_out(tab, ob.op_first, ob.op_count, t) : t * ob.scale);
+                            if (hit && !(ORD_T && (fl & F_TORD) && best.obj != MISS && t_out == wtmax && oi < best.obj)) {
                                 best.obj = oi; best.prim = 0; best.t_local = t; best.u = u; best.v = v;
-                                wtmax = (GENERIC_XF && (fl & F_GENXF)) ? ops_t_out(tab, ob.op_first, ob.op_count, t) : t * ob.scale;
+                                wtmax = t_out;
                             }
                         }
                     }

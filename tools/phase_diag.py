@@ -23,15 +23,18 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--cam", default="1080x960")
     ap.add_argument("--opt", default="")
-    ap.add_argument("--scene", default="bunny", choices=["bunny", "spheres", "grid", "terrain"])
+    ap.add_argument("--scene", default="bunny", choices=["bunny", "spheres", "grid", "terrain", "merged", "flat"])
+    ap.add_argument("--grid", type=int, default=230, help="instances per side of the grid scenes")
     args = ap.parse_args()
     rt = entry.load_package()
     w, h = map(int, args.cam.split("x"))
     sky = rt.load_skybox(max_width=2048)
     make = {"bunny": lambda: rt.Scene.main(sky=sky, cam=(w, h)), "spheres": lambda: rt.Scene.spheres(n=10000, seed=1, sky=sky, cam=(w, h)),
-            "grid": lambda: rt.Scene.grid(230, 230, sky=sky, cam=(w, h)), "terrain": lambda: rt.Scene.terrain(300, seed=1, with_bunny=True, sky=sky, cam=(w, h))}
+            "grid": lambda: rt.Scene.grid(args.grid, args.grid, sky=sky, cam=(w, h)),
+            "merged": lambda: rt.Scene.grid(args.grid, args.grid, sky=sky, cam=(w, h), flat=3), "flat": lambda: rt.Scene.grid(args.grid, args.grid, sky=sky, cam=(w, h), flat=1), "terrain": lambda: rt.Scene.terrain(300, seed=1, with_bunny=True, sky=sky, cam=(w, h))}
     scene = make[args.scene]().upload(0)
-    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH}
+    opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH,
+               "ordered": rt.OPT_ORDERED_WALK, "deepen": rt.OPT_TREE_DEEPENING}
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
         scene.set_option(opt_ids[k], int(v))
