@@ -29,6 +29,7 @@ OPT_TREE_DEEPENING = 10
 OPT_LEAN_KERNELS = 11
 OPT_ORDERED_WALK = 12
 OPT_STRICT_ORDER = 13
+OPT_ORDERED_STACK = 14
 
 _f32p = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)

@@ -29,6 +29,7 @@ struct rtamd_context {
     int deepen = 1;          // object-tree walks in passes of growing reach (rt_sched.h): 0 never, 1 in the render entry points, 2 also in the batch entry points
     int ordered = 1;         // walks that visit the nearer child first (rt_sched.h): same three values
     uint32_t ordered_ok = 0; // ORD_MESH / ORD_TREE: the uploaded scene's trees allow them
+    uint32_t ordered_cap = 15; // stack entries an ordered walk may use (RTAMD_OPT_ORDERED_STACK)
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
@@ -414,6 +415,10 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
         case RTAMD_OPT_ORDERED_WALK:
             if (value < 0 || value > 2) return fail(ctx, RTAMD_E_INVALID, "ordered walk mode must be 0, 1 or 2");
             ctx->ordered = (int)value; ctx->S.ordered = ctx->ordered >= 1 ? ctx->ordered_ok : 0u;
+            return RTAMD_OK;
+        case RTAMD_OPT_ORDERED_STACK:
+            if (value < 0 || value > 15) return fail(ctx, RTAMD_E_INVALID, "ordered stack entries must be in [0, 15]");
+            ctx->ordered_cap = (uint32_t)value; ctx->S.ordered_cap = ctx->ordered_cap;
             return RTAMD_OK;
         case RTAMD_OPT_STRICT_ORDER:
             ctx->deepen = value != 0 ? 0 : 1; ctx->S.deepen = ctx->deepen >= 1 ? 1u : 0u;
@@ -828,6 +833,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     S.deepen = ctx->deepen >= 1 ? 1u : 0u;   // what the render entry points pass to their kernels; the batch entry points decide per call
     ctx->ordered_ok = (pairs_meshes ? ORD_MESH : 0u) | ORD_TREE;   // (object trees carry their own flag, DevTree::deepen)
     S.ordered = ctx->ordered >= 1 ? ctx->ordered_ok : 0u;
+    S.ordered_cap = ctx->ordered_cap;
     ctx->S = S;
     ctx->have_scene = true;
     return RTAMD_OK;

@@ -120,6 +120,7 @@ struct DevScene {
     // behind a left leaf.
     const float4* wide;
     uint32_t ordered;         // ORD_MESH: mesh trees in global memory are walked nearer child first; ORD_TREE: object trees flagged TREE_ORDERED too
+    uint32_t ordered_cap;     // entries of the ordered walks' per-lane stack a walk may use (at most what the kernel instance holds)
 };
 static constexpr uint32_t ORD_MESH = 1u, ORD_TREE = 2u;
 

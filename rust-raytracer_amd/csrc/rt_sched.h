@@ -388,6 +388,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     const bool ord_m = ORD_M && (S.ordered & ORD_MESH) != 0u, ord_t = ORD_T && (S.ordered & ORD_TREE) != 0u;   // wave-uniform
     // the object tree leaves two entries to the mesh walks inside it
     constexpr uint32_t SD_T = ORD_M ? (SD > 2u ? SD - 2u : 0u) : SD;
+    const uint32_t cap_m = SD < S.ordered_cap ? SD : S.ordered_cap, cap_t = SD_T < S.ordered_cap ? SD_T : S.ordered_cap;   // wave-uniform
     const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = (chunk_and_share >> 16) & 0xFu;
     const uint32_t lane = lane_id();
     constexpr uint32_t FEAT = sched_features(MESHLOC, LEAN);
@@ -568,7 +569,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         const uint32_t spt = ORD_T ? (fl >> SPT_SHIFT) & SP_MASK : 0u;
         bool range = (fl & F_MRANGE) != 0u, leaf, done;
         uint32_t first = 0u, end = 0u;
-        ordered_step<!PLAIN_NODE>(S.nodes + 2 * (size_t)node_off, S.wide + 4 * (size_t)node_off, opos, oinv, otmax, n_i, n_n, spm, SD - spt, range,
+        ordered_step<!PLAIN_NODE>(S.nodes + 2 * (size_t)node_off, S.wide + 4 * (size_t)node_off, opos, oinv, otmax, n_i, n_n, spm, cap_m > spt ? cap_m - spt : 0u, range,
                                   ostack + 2u * lane + 128u * spt, leaf, first, end, done);
         fl = (fl & ~(F_MRANGE | (SP_MASK << SPM_SHIFT))) | (range ? F_MRANGE : 0u) | (spm << SPM_SHIFT) | (done ? F_PEND : 0u);
         k_cur = leaf ? first : k_cur; k_end = leaf ? end : k_end;
@@ -782,7 +783,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 uint32_t spt = (fl >> SPT_SHIFT) & SP_MASK;
                 bool range = (fl & F_TRANGE) != 0u, leaf, done;
                 uint32_t first = 0u, end = 0u;
-                ordered_step<EXACT>(S.nodes + 2 * (size_t)t_base, S.wide + 4 * (size_t)t_base, wpos, winv, wtmax, t_i, t_n, spt, SD_T, range, ostack + 2u * lane,
+                ordered_step<EXACT>(S.nodes + 2 * (size_t)t_base, S.wide + 4 * (size_t)t_base, wpos, winv, wtmax, t_i, t_n, spt, cap_t, range, ostack + 2u * lane,
                                     leaf, first, end, done);
                 fl = (fl & ~(F_TRANGE | (SP_MASK << SPT_SHIFT))) | (range ? F_TRANGE : 0u) | (spt << SPT_SHIFT);
                 o_cur = leaf ? t_first + first : o_cur; o_end = leaf ? t_first + end : o_end;
