@@ -12,6 +12,7 @@
 namespace orc {
 
 thread_local Counters g_cnt;
+thread_local std::vector<float>* g_path_log = nullptr;
 
 static const float PI_F = 3.14159265358979323846f;  // std::f32::consts::PI
 
@@ -934,7 +935,13 @@ Color WhittedIntegrator::integrate_recur(const Scene& scene, const Ray& ray, int
     if (depth >= max_depth) return scene.calculate_background(ray);
     HitResult hit;
     g_cnt.closest_rays++;
-    if (!scene.root->hit(ray, 1e12f, hit)) return scene.calculate_background(ray);
+    const bool found = scene.root->hit(ray, 1e12f, hit);
+    if (g_path_log) {
+        const float rec[11] = {(float)depth, found ? (float)hit.obj : -1.0f, found ? (float)hit.prim : 0.0f, found ? (float)hit.material->kind : -1.0f,
+                               found ? hit.t : 0.0f, ray.pos[0], ray.pos[1], ray.pos[2], ray.dir[0], ray.dir[1], ray.dir[2]};
+        g_path_log->insert(g_path_log->end(), rec, rec + 11);
+    }
+    if (!found) return scene.calculate_background(ray);
 
     Color color = V3::fill(0.0f);
     float u = hit.uv[0], v = hit.uv[1];

@@ -204,6 +204,9 @@ struct Counters {
     void cuboid() { cuboids_tested++; if (in_any) cuboids_tested_any++; }
 };
 extern thread_local Counters g_cnt;
+// Diagnostic (not in the reference): when set, integrate_recur appends one record per closest-hit ray of the calling thread:
+// {depth, object (-1: miss), primitive, material kind (-1: miss), t, origin xyz, direction xyz} = 11 floats.
+extern thread_local std::vector<float>* g_path_log;
 
 struct Geometry {
     virtual ~Geometry() {}

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE -- C entry points of the CPU oracle (ctypes-friendly).
 // Scene scripts restate src/main.rs:22-97 of the reference (asset paths supplied by the caller)
 // and add the two synthetic scenes used by the larger benchmark configurations.
+#include <cstring>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -570,6 +571,21 @@ double orc_render(void* p, const int params[4], int x0, int y0, int w, int h, fl
     for (auto& c : per) total.add(c);
     export_counters(total, counters);
     return sec;
+}
+// Diagnostic: the closest-hit rays of one pixel in the order the recursion traces them (see g_path_log): up to max_records
+// records of 11 floats; returns the number of records the pixel produced.  rgb receives the pixel.
+int orc_pixel_path(void* p, const int params[4], int cx, int cy, float* records, int max_records, float rgb[3]) {
+    OrcScene* s = (OrcScene*)p;
+    WhittedIntegrator integ;
+    integ.max_depth = params[0]; integ.shadow_rays = params[1]; integ.scatter_rays = params[2]; integ.antialiasing = params[3];
+    std::vector<float> log;
+    g_path_log = &log;
+    const Color c = integ.calculate_pixel(s->scene, (size_t)cx, (size_t)cy);
+    g_path_log = nullptr;
+    rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
+    const int n = (int)(log.size() / 11);
+    std::memcpy(records, log.data(), sizeof(float) * 11 * (size_t)(n < max_records ? n : max_records));
+    return n;
 }
 // render.rs:62-72 quantiser
 void orc_quantize(const float* rgb, size_t n, uint8_t* out) {

@@ -65,6 +65,7 @@ def lib():
         _lib.orc_render.restype = C.c_double
         _lib.orc_render.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, _u64p]
         _lib.orc_quantize.argtypes = [_f32p, C.c_size_t, _u8p]
+        _lib.orc_pixel_path.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, _f32p, C.c_int, _f32p]
     return _lib
 
 
@@ -215,6 +216,16 @@ class OracleScene:
         cnt = np.zeros(12, np.uint64)
         sec = lib().orc_render(self.h, params, x0, y0, w, h, _fp(out), threads, cnt.ctypes.data_as(_u64p))
         return out, sec, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+
+def pixel_path(scene, cx, cy, max_depth=5, shadow_rays=1, scatter_rays=1, antialiasing=1, max_records=4096):
+    """Diagnostic: the closest-hit rays of one pixel in the order the recursion traces them, as rows of
+    (depth, object or -1, primitive, material kind or -1, t, origin xyz, direction xyz), and the pixel's colour."""
+    rec = np.zeros((max_records, 11), np.float32)
+    rgb = np.zeros(3, np.float32)
+    params = (C.c_int * 4)(max_depth, shadow_rays, scatter_rays, antialiasing)
+    n = lib().orc_pixel_path(scene.h, params, cx, cy, _fp(rec), max_records, _fp(rgb))
+    return rec[:min(n, max_records)], rgb
 
 
 def quantize(rgb):
