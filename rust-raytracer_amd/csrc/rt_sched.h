@@ -170,6 +170,22 @@ __device__ unsigned long long g_timeline_launch[TL_LAUNCH_SLOTS * TL_MAX_WAVES *
 #define TL_FLUSH
 #endif
 
+// Attribution build only (-DRTAMD_LDS_DUP=<bits>): the LDS accesses of one kind are issued a second time, into registers that
+// nothing uses, so that the growth of SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE over the plain build is that kind's share (results
+// and control flow stay what they are).  1 node records, 2 triangle records, 4 staged rays, 8 owner marks of the triangle phase,
+// 16 its result slots (atomic minimum + read-back).  Never compiled into librtamd.so.
+#ifndef RTAMD_LDS_DUP
+#define RTAMD_LDS_DUP 0
+#endif
+#ifndef RTAMD_TRI_LANE_PERM
+#define RTAMD_TRI_LANE_PERM 0
+#endif
+__device__ __forceinline__ void lds_dup4(lds_float4* p) {
+    typedef volatile __attribute__((address_space(3))) const v4f* vp;
+    const v4f v = *(vp)p;
+    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+}
+
 // Claims the next chunk of the work queue for the wave (one atomic per chunk).
 __device__ __forceinline__ uint32_t claim_chunk(uint32_t* work_head, uint32_t chunk) {
     uint32_t base = 0;
@@ -507,6 +523,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         if (MESHLOC == MESH_LDS || (MESHLOC == MESH_MIXED && (fl & F_MLDS))) {
             lds_float4* np = lds.nodes + 2 * n_i;
             n0 = lds_load4(np); n1 = lds_load4(np + 1);
+            if (RTAMD_LDS_DUP & 1) { lds_dup4(np); lds_dup4(np + 1); }
         } else {
             const float4* np = S.nodes + 2 * ((size_t)node_off + n_i);
             n0 = np[0]; n1 = np[1];
@@ -608,13 +625,31 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 mark[lane] = 0u;
                 const uint32_t lo = off > base ? off : base;
                 if (is_tri && lo < off + cnt && lo < base + 64u) mark[lo - base] = lane + 1u;
+                if (RTAMD_LDS_DUP & 8) {
+                    if (is_tri && lo < off + cnt && lo < base + 64u) mark[lo - base] = lane + 1u;
+                    const uint32_t z = mark[lane];
+                    asm volatile("" ::"v"(z));
+                }
                 return wave_scan_max(mark[lane]);
             };
             struct Pair { uint32_t o, k, tri_off; bool valid, in_lds; f3 pos, dir; float tmax; };
             // the owner's ray and leaf position, pulled over to the lane that tests the pair
-            auto pull_pair = [&](const uint32_t base, const uint32_t owner1) -> Pair {
+            auto pull_pair = [&](const uint32_t base, const uint32_t owner_in_order) -> Pair {
                 Pair P;
-                const uint32_t p = base + lane;
+                // Which pair of the round a lane tests.  A 16-byte LDS read is served in four groups of sixteen lanes that are not
+                // consecutive lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same in the upper half); only lanes of one
+                // group can collide on a bank, and consecutive 48-byte triangle records never do.  With pair = lane a group's
+                // sixteen lanes read pieces of up to three leaves; with the pairs dealt so that a group reads sixteen consecutive
+                // pairs it is one leaf, or the end of one and the start of the next.
+                uint32_t pl = lane, owner1 = owner_in_order;
+                if (RTAMD_TRI_LANE_PERM && MESHLOC != MESH_GLOBAL) {
+                    const uint32_t l5 = lane & 31u;
+                    const bool g1 = (l5 >= 4u && l5 < 12u) || (l5 >= 16u && l5 < 20u) || l5 >= 28u;
+                    const uint32_t pos = l5 < 4u ? l5 : (l5 < 12u ? l5 - 4u : (l5 < 20u ? l5 - 8u : (l5 < 28u ? l5 - 12u : l5 - 16u)));
+                    pl = (lane & 32u) + (g1 ? 16u : 0u) + pos;
+                    owner1 = lane_pull(pl, owner_in_order);
+                }
+                const uint32_t p = base + pl;
                 P.valid = p < total;
                 P.o = P.valid ? owner1 - 1u : 0u;
                 const uint32_t k = lane_pull(P.o, kbase) + p;
@@ -636,6 +671,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     q0 = lds_load4(tp); q1 = lds_load4(tp + 1);
                     // only ac.z of the third quad is needed (the rest are vertex ids for the shade stage)
                     q2 = make_float4(((__attribute__((address_space(3))) const float*)tp)[8], 0.f, 0.f, 0.f);
+                    if (RTAMD_LDS_DUP & 2) {
+                        lds_dup4(tp); lds_dup4(tp + 1);
+                        const float z = ((volatile __attribute__((address_space(3))) const float*)tp)[8];
+                        asm volatile("" ::"v"(z));
+                    }
                 } else {
                     const float4* tp = S.tris + 3 * ((size_t)P.tri_off + P.k);
                     q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
@@ -647,6 +687,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 const unsigned long long my_key = ((unsigned long long)t_key << 32) | (unsigned long long)(0xFFFFFFFFu - P.k);
                 if (hit) {
                     __hip_atomic_fetch_min((lds_u64*)(coop + 64) + P.o, my_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (RTAMD_LDS_DUP & 16) {
+                        __hip_atomic_fetch_min((lds_u64*)(coop + 64) + P.o, my_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const unsigned long long z = slot[P.o];
+                        asm volatile("" ::"v"((uint32_t)z), "v"((uint32_t)(z >> 32)));
+                    }
                     if (slot[P.o] == my_key) { pay[P.o] = __float_as_uint(t); pay[64 + P.o] = __float_as_uint(u); pay[128 + P.o] = __float_as_uint(v); }
                 }
             };
@@ -1015,6 +1060,10 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 const uint32_t src = (sg_pos + rank) & 63u;
 #pragma unroll
                 for (int c = 0; c < 8; c++) raw[c] = stage[c * 64 + src];
+                if (RTAMD_LDS_DUP & 4) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) { const uint32_t z = ((volatile lds_u32*)stage)[c * 64 + src]; asm volatile("" ::"v"(z)); }
+                }
             }
             { DIAG_SUB_BEGIN
             if (want && (fl & F_HAVE)) {
