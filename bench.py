@@ -61,6 +61,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4
 VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0   # one wave64 VALU instruction per SIMD every 2 cycles: 1228.8 G wave-instructions/s
+VALU_MEASURED_GINST = 856.0      # what this chip sustains on independent v_fma_f32 with >= 2 waves per SIMD (profiles/r02/valu_issue_probe.txt)
+N_CU = 256
+LDS_PEAK_TBS = 150.0             # every CU streaming ds_read_b64 / b128: 256 B per clock per CU
+L2_PEAK_GBS = 34500.0            # aggregate L2 bandwidth
 TRACE_KERNEL = "k_wave_trace"
 
 
@@ -127,7 +131,8 @@ def byte_model(cnt):
 PMC_PASSES = (
     ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY"]),
     ("fetch", ["FETCH_SIZE", "TCC_HIT_sum"]),
-    ("write", ["WRITE_SIZE", "TCC_MISS_sum"]),
+    ("write", ["WRITE_SIZE", "TCC_MISS_sum", "TCC_REQ_sum"]),
+    ("lds", ["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS"]),
 )
 
 
@@ -147,7 +152,7 @@ def run_pmc_passes(argv_inner, timeout_s=150):
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s + 30)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
-                return None
+                continue   # (this pass's figures stay null; the others are kept)
             seen = {}
             for r in csv.DictReader(open(files[0])):
                 if TRACE_KERNEL in r["Kernel_Name"]:
@@ -157,18 +162,19 @@ def run_pmc_passes(argv_inner, timeout_s=150):
             for k, (s, disp) in seen.items():
                 out[k] = (s, len(disp))
         except Exception:
-            return None
+            continue
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return out or None
 
 
 def self_launch(n):
-    """`python bench.py --gpus N` from a plain shell: start N ranks as children.  Nothing here touches the GPU."""
+    """`python bench.py --gpus N` from a plain shell: start N ranks as children (this process never replaces itself
+    with another program, so it does not matter whether counting the devices initialises the GPU runtime)."""
     import torch
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if torch.cuda.device_count() < n:   # counting devices does not initialise the GPU
+    if torch.cuda.device_count() < n:
         env.setdefault("RTAMD_BENCH_BACKEND", "gloo")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -266,9 +272,17 @@ def main():
     tiles = torch.zeros((n_px // (TILE * TILE), TILE, TILE, 3), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
+    split = {"render_s": 0.0, "gather_s": 0.0}   # this rank's share of the timed region (N > 1: reported per rank)
+
     def step():
-        _, st = scene.render(max_depth=max_depth, shadow_rays=shadow_rays, antialiasing=aa, region=region, out_device=tiles)
+        t_a = time.perf_counter()
+        _, st = scene.render(max_depth=max_depth, shadow_rays=shadow_rays, antialiasing=aa, region=region, out_device=tiles)   # returns when the frame is complete
+        t_b = time.perf_counter()
         img = dist_tiles.gather_frame(tiles, W, H, TILE, TILE, rank, world)
+        if world > 1:
+            torch.cuda.synchronize()
+        split["render_s"] += t_b - t_a
+        split["gather_s"] += time.perf_counter() - t_b
         return st, img
 
     def barrier():
@@ -285,6 +299,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    split["render_s"] = split["gather_s"] = 0.0
     t0 = time.perf_counter()
     rays = 0
     dev_ms = 0.0
@@ -296,7 +311,12 @@ def main():
     elapsed = time.perf_counter() - t0
     closest_per_step, any_per_step, paths_per_step = st["closest_rays"], st["any_rays"], st["paths"]
 
+    per_rank = None
     if world > 1:
+        mine = {"rank": rank, "device": dev_index, "owned_tiles": n_px // (TILE * TILE), "render_ms_per_step": split["render_s"] / args.steps * 1e3,
+                "gather_ms_per_step": split["gather_s"] / args.steps * 1e3, "rays_per_step": float(st["closest_rays"] + st["any_rays"])}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([elapsed, float(rays), float(closest_per_step), float(any_per_step), float(paths_per_step)], dtype=torch.float64,
                          device=dev if backend == "nccl" else "cpu")
         tmax = t.clone()
@@ -350,14 +370,32 @@ def main():
             if pmc and "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
                 l2_hit = pmc["TCC_HIT_sum"][0] / max(1.0, pmc["TCC_HIT_sum"][0] + pmc["TCC_MISS_sum"][0])
             achieved = valu_per_ray * rays_per_s / 1e9 if valu_per_ray else None
+            # the levels the nodes and triangles are actually served from: LDS-array cycles (every cycle moves up to 256 B per CU)
+            # against the CUs' cycles of the launch, and L2 requests (at most 128 B each) against the L2's aggregate bandwidth
+            lds = l2 = None
+            if pmc and "SQ_LDS_IDX_ACTIVE" in pmc:
+                cu_cycles = N_CU * CLOCK_GHZ * 1e9 * trace_ms * 1e-3
+                idx = pmc["SQ_LDS_IDX_ACTIVE"][0]
+                lds = {"array_busy_frac": idx / cu_cycles, "bank_conflict_share_of_array_cycles": pmc["SQ_LDS_BANK_CONFLICT"][0] / max(1.0, idx),
+                       "array_cycles_per_ray": idx / n_rays, "lds_wave_insts_per_ray": pmc["SQ_INSTS_LDS"][0] / n_rays,
+                       "bytes_upper_tbs": idx * 256.0 / (trace_ms * 1e-3) / 1e12, "peak_tbs": LDS_PEAK_TBS,
+                       "note": "SQ_LDS_IDX_ACTIVE = LDS-array cycles, each serving up to 256 B; busy = those cycles / (256 CUs x 2.4 GHz x kernel time)"}
+            if pmc and "TCC_REQ_sum" in pmc:
+                req_gbs = pmc["TCC_REQ_sum"][0] * 128.0 / (trace_ms * 1e-3) / 1e9
+                l2 = {"requests_per_ray": pmc["TCC_REQ_sum"][0] / n_rays, "gbs_upper": req_gbs, "peak_gbs": L2_PEAK_GBS, "frac_upper": req_gbs / L2_PEAK_GBS,
+                      "note": "TCC_REQ_sum x 128 B (the most a request moves) / kernel time"}
             roofline = {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
                         "frac": achieved / VALU_PEAK_GINST if achieved else None, "traffic": hbm_bytes,
+                        "peak_measured": VALU_MEASURED_GINST, "frac_of_measured_issue_ceiling": achieved / VALU_MEASURED_GINST if achieved else None,
+                        "lds": lds, "l2": l2,
                         "kernel": "k_wave_trace (persistent closest-hit + any-hit traversal of the wavefront queues)",
                         "avg_launch_ms": avg_ms, "launches": n_launch, "rays_per_launch": rays_per_launch,
                         "valu_wave_insts_per_ray": valu_per_ray, "valu_lane_utilisation": lane_util,
                         "note": "bound = vector-instruction issue + LDS/L2 latency (tree and triangles are LDS- or L2-resident); "
-                                "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; hbm_* = measured HBM traffic of the same "
-                                "kernel against the 8 TB/s peak; algorithmic_* = the reference-order byte model, mostly served from LDS/L2",
+                                "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (peak_measured: what independent v_fma_f32 "
+                                "streams sustain on this chip); hbm_* = measured HBM traffic of the same kernel against the 8 TB/s peak; lds / l2 = "
+                                "the levels the tree is served from; algorithmic_* = the reference-order byte model (bytes the reference's walk "
+                                "would touch per ray; served from LDS / L2 here, so its rate is not bounded by the HBM peak)",
                         "hbm_gbs": hbm_bytes / (avg_ms * 1e-3) / 1e9 if hbm_bytes else None,
                         "hbm_frac": hbm_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if hbm_bytes else None,
                         "l2_hit_rate": l2_hit,
@@ -365,8 +403,7 @@ def main():
             if cnt is not None:
                 b_closest, b_any = byte_model(cnt)
                 alg = (st["closest_rays"] * b_closest + st["any_rays"] * b_any) / (trace_ms * 1e-3) / 1e9
-                roofline.update({"algorithmic_bytes_per_closest_ray": b_closest, "algorithmic_bytes_per_any_ray": b_any,
-                                 "algorithmic_gbs": alg, "algorithmic_frac_of_hbm_peak": alg / HBM_PEAK_GBS})
+                roofline.update({"algorithmic_bytes_per_closest_ray": b_closest, "algorithmic_bytes_per_any_ray": b_any, "algorithmic_gbs": alg})
             extra["trace_kernel_mrays_per_s"] = rays_per_s / 1e6
             extra["stage_ms_per_frame"] = {"trace": trace_ms, "shade_resolve": st["shade_ms"], "device_total": st["device_ms"]}
 
@@ -387,6 +424,18 @@ def main():
             "rays_per_step": {"closest": closest_per_step, "any": any_per_step, "paths": paths_per_step},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if per_rank is not None:
+            r_ms = [p["render_ms_per_step"] for p in per_rank]
+            g_ms = [p["gather_ms_per_step"] for p in per_rank]
+            line["multi_gpu"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "devices": sorted({p["device"] for p in per_rank}),
+                                 "per_rank_render_ms": {"min": min(r_ms), "max": max(r_ms)}, "gather_ms": {"min": min(g_ms), "max": max(g_ms), "rank0": g_ms[0]},
+                                 "owned_tiles": [p["owned_tiles"] for p in per_rank], "rays_per_rank": [p["rays_per_step"] for p in per_rank],
+                                 "note": "render = this rank's tiles through the wavefront kernels (blocking); gather = the framebuffer gather to rank 0 "
+                                         "(a rank that finishes early waits here for the slowest); ms_per_step is the slowest rank's total"}
+        line["config"]["strong_scaling_workloads"] = ("spheres_10k_3840x2160_64spp_depth5 and bunny_grid_230x230_7680x4320_256spp_depth5 (BASELINE configs[3], [4]) are the "
+                                                      "frames meant for 2 / 4 / 8 GPUs: a pixel's samples are sequential (one random stream per pixel, integrator.rs:36), so a "
+                                                      "frame is spp x max_depth dependent launch steps whatever the tile count, and the 1080x960 frame cut in eight runs "
+                                                      "every step at its latency floor")
         line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
