@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
         else aa = std::atoi(argv[i]);
     }
     try {
+        bvh_print_stats_enabled() = true;   // AABBTree::new prints its statistics (bvh.rs:173-177)
         std::shared_ptr<const Image> skybox;
         if (!sky.empty()) skybox = Image::open_ppm(sky);
         Scene scene = scene_main(ply, skybox, w, h);

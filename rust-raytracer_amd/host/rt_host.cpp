@@ -259,6 +259,17 @@ struct Builder {
 };
 }  // namespace
 
+bool& bvh_print_stats_enabled() {
+    static bool on = false;
+    return on;
+}
+// AABBTree::print_stats (bvh.rs:179-204): the line the reference prints after every AABBTree::new.
+void print_stats(const BvhTree& t) {
+    uint32_t s[5];
+    bvh_statistics(t, s);
+    std::printf("BVH statistics: %u objs, %u nodes, %u leafs, min/max/avg leaf: %u/%u/%g\n", s[0], s[1], s[2], s[3], s[4], (double)((float)s[0] / (float)s[2]));
+    std::fflush(stdout);
+}
 BvhTree build_aabb_tree(const std::vector<AABB>& boxes, float hit_cost) {
     Builder b;
     b.box = boxes;
@@ -276,6 +287,7 @@ BvhTree build_aabb_tree(const std::vector<AABB>& boxes, float hit_cost) {
     BvhTree t;
     t.nodes = std::move(b.nodes);
     t.order = std::move(b.order);
+    if (bvh_print_stats_enabled()) print_stats(t);   // bvh.rs:173-177
     return t;
 }
 BvhTree build_aabb_tree(Device& dev, const std::vector<AABB>& boxes, float hit_cost) {
@@ -291,6 +303,7 @@ BvhTree build_aabb_tree(Device& dev, const std::vector<AABB>& boxes, float hit_c
     uint32_t n_nodes = 0;
     dev.check(rtamd_build_bvh(dev.ctx, flat.data(), (uint32_t)boxes.size(), hit_cost, t.nodes.data(), &n_nodes, t.order.data()), "rtamd_build_bvh");
     t.nodes.resize(n_nodes);
+    if (bvh_print_stats_enabled()) print_stats(t);
     return t;
 }
 void bvh_statistics(const BvhTree& t, uint32_t out[5]) {
@@ -899,7 +912,10 @@ void load_ply(const std::string& path, std::vector<Vec3D>& vertices, std::vector
                     }
                     const size_t sp = type.find(' ', 5);
                     const std::string count_type = type.substr(5, sp - 5), item_type = type.substr(sp + 1);
-                    if (!read_scalar(f, count_type, be, v, fv) || v < 0) throw err("unexpected end of the binary body");
+                    // (a list's length is an integer type; a float one could hold a NaN or a value no size_t can)
+                    if (count_type.rfind("float", 0) == 0) throw err("list length of a floating-point type");
+                    if (!read_scalar(f, count_type, be, v, fv)) throw err("unexpected end of the binary body");
+                    if (!(v >= 0.0 && v <= 16777216.0)) throw err("invalid list length");
                     const size_t n = (size_t)v;
                     const bool take = is_face && (int)q == index;
                     if (take && n < 3) throw err("invalid number of vertices");

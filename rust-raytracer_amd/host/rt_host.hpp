@@ -146,6 +146,10 @@ struct BvhTree {  // result of AABBTree::new: nodes incl. sentinel + the permuta
 // Binned-SAH pre-order build with skip links: AABBTree::with_partition + partition_sah,
 // src/geom/bvh.rs:10-171 (including its split-cost expression as written).
 BvhTree build_aabb_tree(const std::vector<AABB>& boxes, float hit_cost);
+// AABBTree::print_stats (bvh.rs:179-204): "BVH statistics: N objs, M nodes, L leafs, min/max/avg leaf: a/b/c".  The reference prints
+// it after every AABBTree::new (bvh.rs:173-177); here the builders print it when bvh_print_stats_enabled() is set (rtamd_main sets it).
+void print_stats(const BvhTree& t);
+bool& bvh_print_stats_enabled();
 struct Device;
 // The same tree, built on the GPU (rtamd_build_bvh): identical nodes and order; worth it from some 10^5 boxes on.
 BvhTree build_aabb_tree(Device& dev, const std::vector<AABB>& boxes, float hit_cost);

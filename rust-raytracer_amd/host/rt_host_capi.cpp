@@ -120,6 +120,8 @@ int rth_scene_tree_size(void* p, int which, uint32_t out[2]) {
     out[0] = (uint32_t)t->nodes.size(); out[1] = (uint32_t)t->order.size();
     return 0;
 }
+// AABBTree::new prints its statistics line (bvh.rs:173-204) from now on (on != 0) or not (the default)
+void rth_set_print_stats(int on) { rth::bvh_print_stats_enabled() = on != 0; }
 int rth_scene_tree_dump(void* p, int which, uint32_t* nodes8, uint32_t* order, uint32_t stats[5]) {
     Handle* h = (Handle*)p;
     const BvhTree* t = nullptr;

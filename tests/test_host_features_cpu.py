@@ -97,3 +97,21 @@ def test_flat_grid_and_scatter_scenes_match_the_oracle_on_the_host(rt, ol, sky):
     gn, _, gs = rt.Scene.scatter(40, seed=2, accelerate=True, sky=sky, cam=(64, 48)).tree(1)
     cn, _, cs = ol.OracleScene.scatter(40, seed=2, accelerate=True, sky=sky, cam=(64, 48)).bvh(1)
     assert np.array_equal(gn, cn) and np.array_equal(gs, cs) and gs[0] == 40
+
+
+def test_tree_builder_prints_the_reference_statistics_line(rt, capfd):
+    """AABBTree::new prints "BVH statistics: ..." (bvh.rs:173-204); the C++ host's builder does when asked to (rtamd_main does)."""
+    rng = np.random.default_rng(3)
+    lo = rng.uniform(-5, 5, (500, 3)).astype(np.float32)
+    boxes = np.concatenate([lo, lo + rng.uniform(0.01, 0.5, (500, 3)).astype(np.float32)], axis=1)
+    rt.host_lib().rth_set_print_stats(1)
+    try:
+        nodes, order, _ = rt.build_tree(boxes, hit_cost=1.0)
+    finally:
+        rt.host_lib().rth_set_print_stats(0)
+    out = capfd.readouterr().out
+    sizes = nodes[1:, 7].astype(np.int64) - nodes[:-1, 7].astype(np.int64)
+    leaf = sizes[sizes > 0]
+    assert f"BVH statistics: 500 objs, {len(nodes)} nodes, {len(leaf)} leafs, min/max/avg leaf: {leaf.min()}/{leaf.max()}/" in out
+    rt.build_tree(boxes, hit_cost=1.0)
+    assert "BVH statistics" not in capfd.readouterr().out
