@@ -785,6 +785,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
             if (bytes > 0 && bytes <= 52 * 1024 && refs[m] > best_refs) { S.lds_mesh = m; S.lds_bytes = (uint32_t)bytes; best_refs = refs[m]; }
         }
         if (S.lds_mesh != MISS && (uint64_t)best_refs * 4u < mesh_objects) { S.lds_mesh = MISS; S.lds_bytes = 0; }
+        S.lds_sched_bytes = S.lds_mesh != MISS ? lds_mesh_bytes(meshes[S.lds_mesh].n_nodes, sc->meshes[S.lds_mesh].n_tris) : 0u;
     }
     // Scene tables small enough for LDS (objects, ops, cuboids, root list): at most 8 KiB
     S.n_ops = sc->n_ops; S.n_cuboids = sc->n_cuboids;
@@ -814,6 +815,9 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
     {   // large scenes: classes, cuboids, tree headers and the root list in LDS (at most 8 KiB), instance records in global memory
         size_t mb = classes.size() * sizeof(DevObject) + (size_t)sc->n_cuboids * 48 + (size_t)sc->n_trees * 16 + (((size_t)sc->n_root * 8 + 15) & ~(size_t)15);
         S.mid_bytes = (S.tab_bytes == 0 && !classes.empty() && mb <= 8192) ? (uint32_t)mb : 0u;
+        // (beside a staged mesh those kernel instances hold 40 KB of fixed LDS -- ray staging, triangle phase, ordered-walk stack --
+        // and two blocks share a CU's 160 KB: mesh + tables must fit the other 40 KB, else the tables stay in global memory)
+        if (S.lds_sched_bytes + S.mid_bytes > 40u * 1024u) S.mid_bytes = 0u;
     }
     if (std::getenv("RTAMD_VERBOSE")) {
         size_t classed = 0;

@@ -28,6 +28,9 @@ static constexpr uint32_t LEAF_BIT = 0x80000000u;
 static constexpr uint32_t MISS = 0xFFFFFFFFu;
 
 struct DevMesh { uint32_t node_base, n_nodes, tri_base, normal_base; };   // n_nodes excludes the sentinel
+// LDS bytes of a mesh as the scheduler kernels stage it: 32-byte nodes, then per triangle two 16-byte quads and one float, each in a
+// plane of its own (the float plane rounded up to a whole quad)
+__host__ __device__ inline uint32_t lds_mesh_bytes(uint32_t n_nodes, uint32_t n_tris) { return 32u * n_nodes + 32u * n_tris + ((4u * n_tris + 15u) & ~15u); }
 // deepen: bits 0-1 walk in passes of growing reach (rt_sched.h; 1 a tree of meshes, 2 a tree of cheap objects), bit 2 (TREE_ORDERED)
 // the tree may be walked nearer child first (every object a mesh, a sphere or a triangle, the tree strictly binary)
 struct DevTree { uint32_t node_base, n_nodes, first_object, deepen; };
@@ -100,7 +103,8 @@ struct DevScene {
     uint32_t n_objects, n_meshes;
     uint32_t root_first;      // root list = plain objects root_first, root_first + 1, ...: that first index; else MISS
     uint32_t lds_mesh;        // mesh index staged in LDS by the trace kernels, or MISS
-    uint32_t lds_bytes;       // bytes of LDS needed for that mesh
+    uint32_t lds_bytes;       // bytes of that mesh as global memory holds it (32-byte nodes + 48-byte triangles): what the plain kernels stage
+    uint32_t lds_sched_bytes; // bytes of LDS the scheduler kernels need for it (36 bytes per triangle, see LdsMesh)
     uint32_t n_ops, n_cuboids;
     uint32_t any_box;         // some object carries XF_BOX: rays get their reciprocal direction when they are fetched
     uint32_t features;        // FEAT_* bits of the object kinds and wrapper chains present

@@ -115,25 +115,48 @@ __device__ __forceinline__ void block_copy_end(const T (&v)[D], T* dst, const T*
     for (uint32_t i = threadIdx.x + (uint32_t)D * blockDim.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+__device__ __forceinline__ uint32_t n_node4_of(const DevScene& S) { return 2u * S.meshes[S.lds_mesh].n_nodes; }
 template <int MESHLOC, int TABKIND>
 __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, LdsTab& ltab, MidTab& mtab) {
     uint32_t base = 0;  // float4 offset
     lds.nodes = (lds_float4*)g_lds;
     lds.tris = (lds_float4*)g_lds;
+    lds.tris1 = (lds_float4*)g_lds;
+    lds.trisz = (__attribute__((address_space(3))) const float*)g_lds;
     constexpr bool MESH = MESHLOC == MESH_LDS || MESHLOC == MESH_MIXED;
+    uint32_t n_tris = 0;
+    // the staged mesh's triangles go to three planes (see LdsMesh): quad c of triangle k lands in plane c
+    auto store_tris = [&](const float4 (&v)[8], const float4* src, uint32_t n4) {
+        float4* q0 = g_lds + n_node4_of(S);
+        float4* q1 = q0 + n_tris;
+        float* z = (float*)(q1 + n_tris);
+        auto put = [&](uint32_t i, const float4& q) {
+            const uint32_t k = i / 3u, c = i - 3u * k;
+            if (c == 0u) q0[k] = q; else if (c == 1u) q1[k] = q; else z[k] = q.x;
+        };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
+            if (i < n4) put(i, v[k]);
+        }
+        for (uint32_t i = threadIdx.x + 8u * blockDim.x; i < n4; i += blockDim.x) put(i, src[i]);
+    };
     float4 vn[2], vt[8], va[1], vb[1], vc[1];
     uint32_t n_node4 = 0, n_tri4 = 0;
     const float4 *gn = nullptr, *gt = nullptr;
     if (MESH) {
         const DevMesh m = S.meshes[S.lds_mesh];
         n_node4 = 2 * m.n_nodes;
-        n_tri4 = S.lds_bytes / 16 - n_node4;
+        n_tri4 = S.lds_bytes / 16 - n_node4;   // (lds_bytes: the mesh as 32-byte nodes + 48-byte triangles, as global memory holds it)
+        n_tris = n_tri4 / 3u;
         gn = S.nodes + 2 * (size_t)m.node_base;
         gt = S.tris + 3 * (size_t)m.tri_base;
         block_copy_begin(vn, gn, n_node4);
         block_copy_begin(vt, gt, n_tri4);
         lds.tris = (lds_float4*)g_lds + n_node4;
-        base = n_node4 + n_tri4;
+        lds.tris1 = lds.tris + n_tris;
+        lds.trisz = (__attribute__((address_space(3))) const float*)(lds.tris1 + n_tris);
+        base = lds_mesh_bytes(m.n_nodes, n_tris) / 16u;
     }
     if (TABKIND == TAB_LDS) {
         const uint32_t n_obj4 = 8 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
@@ -145,7 +168,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         block_copy_begin(vc, gc, n_cub4);
         uint2* lr = (uint2*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
         for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
-        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); block_copy_end(vt, g_lds + n_node4, gt, n_tri4); }
+        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); store_tris(vt, gt, n_tri4); }
         block_copy_end(va, g_lds + base, go, n_obj4);
         block_copy_end(vb, g_lds + base + n_obj4, gp, n_op4);
         block_copy_end(vc, g_lds + base + n_obj4 + n_op4, gc, n_cub4);
@@ -164,7 +187,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         block_copy_begin(vc, gh, n_tree4);
         uint2* lr = (uint2*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
         for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
-        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); block_copy_end(vt, g_lds + n_node4, gt, n_tri4); }
+        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); store_tris(vt, gt, n_tri4); }
         block_copy_end(va, g_lds + base, gk, n_cls4);
         block_copy_end(vb, g_lds + base + n_cls4, gc, n_cub4);
         block_copy_end(vc, g_lds + base + n_cls4 + n_cub4, gh, n_tree4);
@@ -175,7 +198,7 @@ __device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, Lds
         mtab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
     } else if (MESH) {
         block_copy_end(vn, g_lds, gn, n_node4);
-        block_copy_end(vt, g_lds + n_node4, gt, n_tri4);
+        store_tris(vt, gt, n_tri4);
     }
     if (MESH || TABKIND != TAB_GLOBAL) __syncthreads();
 }
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     }
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
     __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][MESHLOC == MESH_NONE ? 1 : COOP_WORDS / 2];   // (the triangle phase's)
-    __shared__ unsigned long long ord_stack[TRACE_BLOCK / 64][sched_stack_depth(MESHLOC) ? 64 * sched_stack_depth(MESHLOC) : 1];
+    __shared__ unsigned long long ord_stack[TRACE_BLOCK / 64][sched_stack_depth(MESHLOC, TABKIND == TAB_LDS) ? 64 * sched_stack_depth(MESHLOC, TABKIND == TAB_LDS) : 1];
     LdsMesh lds;
     LdsTab ltab;
     MidTab mtab;
@@ -668,7 +691,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     const uint32_t chunk = chunk_hint;
     __shared__ uint32_t ray_stage[TRACE_BLOCK / 64][STAGE_WORDS];
     __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][MESHLOC == MESH_NONE ? 1 : COOP_WORDS / 2];   // (the triangle phase's)
-    __shared__ unsigned long long ord_stack[TRACE_BLOCK / 64][sched_stack_depth(MESHLOC) ? 64 * sched_stack_depth(MESHLOC) : 1];
+    __shared__ unsigned long long ord_stack[TRACE_BLOCK / 64][sched_stack_depth(MESHLOC, TABKIND == TAB_LDS) ? 64 * sched_stack_depth(MESHLOC, TABKIND == TAB_LDS) : 1];
     lds_u32* stage = (lds_u32*)ray_stage[threadIdx.x >> 6];
     lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
     lds_u32* ostack = (lds_u32*)ord_stack[threadIdx.x >> 6];
@@ -1375,7 +1398,7 @@ static inline int mesh_location(const DevScene& S, const LaunchCfg& cfg) {
     do {                                                                                                                    \
         const int loc_ = mesh_location(S, cfg);                                                                             \
         const int tab_ = !cfg.use_lds ? TAB_GLOBAL : ((S).tab_bytes > 0 ? TAB_LDS : ((S).mid_bytes > 0 ? TAB_MID : TAB_GLOBAL));  \
-        const uint32_t lb_ = ((loc_ == MESH_LDS || loc_ == MESH_MIXED) ? (S).lds_bytes : 0u) + (tab_ == TAB_LDS ? (S).tab_bytes : (tab_ == TAB_MID ? (S).mid_bytes : 0u)); \
+        const uint32_t lb_ = ((loc_ == MESH_LDS || loc_ == MESH_MIXED) ? (S).lds_sched_bytes : 0u) + (tab_ == TAB_LDS ? (S).tab_bytes : (tab_ == TAB_MID ? (S).mid_bytes : 0u)); \
         const bool lean_ = cfg.lean && ((S).features & ~sched_features(loc_, true)) == 0u;                                    \
         if (loc_ == MESH_NONE) RTAMD_DISPATCH_TAB(KERNEL, MESH_NONE, tab_, lean_, grid, lb_, st, __VA_ARGS__);                \
         else if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, lean_, grid, lb_, st, __VA_ARGS__);             \

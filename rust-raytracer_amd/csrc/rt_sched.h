@@ -31,10 +31,16 @@ enum : uint32_t { ST_FETCH = 0, ST_OBJ = 1, ST_TNODE = 2, ST_NODE = 3, ST_TRI = 
 
 // LDS copy of mesh S.lds_mesh, addressed through LDS-typed pointers so that the loads are
 // ds_read_b128 (a generic pointer that may be LDS or global compiles to slow flat loads).
+// Triangles: what the triangle test reads and nothing else, in three planes: {a.xyz, ab.x} and {ab.yz, ac.xy} as 16-byte
+// records, ac.z as a float (the vertex ids of the 48-byte global record are the shade stage's): 36 bytes per triangle
+// instead of 48, and the consecutive triangles of a leaf, read by consecutive lanes, lie in consecutive banks.
 struct LdsMesh {
     lds_float4* nodes;
-    lds_float4* tris;
+    lds_float4* tris;    // plane of the first quads
+    lds_float4* tris1;   // plane of the second quads
+    __attribute__((address_space(3))) const float* trisz;   // plane of ac.z
 };
+
 // Where the mesh trees of a launch live: decided on the host per scene.
 // MESH_NONE: the scene has no mesh at all (spheres, cuboids, triangles only): the mesh phases are compiled out.
 enum : int { MESH_GLOBAL = 0, MESH_LDS = 1, MESH_MIXED = 2, MESH_NONE = 3 };
@@ -390,15 +396,18 @@ __device__ __forceinline__ bool ordered_leaf_done(uint32_t& ni, const uint32_t n
 __host__ __device__ constexpr uint32_t sched_features(int meshloc, bool lean) {
     return !lean ? FEAT_ALL : (meshloc == MESH_NONE ? (FEAT_SPHERE | FEAT_CUBOID) : FEAT_CUBOID);
 }
-// Entries per lane of the ordered walks' stack (sched_stack_depth(MESHLOC) x 512 bytes per wave), 0: no ordered walks in this
-// instance.  Mesh trees in global memory: what two 512-thread blocks per CU leave of the 160 KB; scenes without meshes run
-// three blocks per CU.  Instances that stage a mesh in LDS have no room (and their tree needs none: it is small).
-__host__ __device__ constexpr uint32_t sched_stack_depth(int meshloc) { return meshloc == MESH_GLOBAL ? 10u : (meshloc == MESH_NONE ? 7u : 0u); }
+// Entries per lane of the ordered walks' stack (sched_stack_depth x 512 bytes per wave), 0: no ordered walks in this instance.
+// Mesh trees in global memory: what two 512-thread blocks per CU leave of the 160 KB; scenes without meshes run three blocks per
+// CU; beside a mesh staged in LDS three entries fit (rtamd_upload_scene keeps mesh + tables within what is left).  Scenes whose
+// tables fit LDS (at most 64 objects) have no tree worth an ordered walk.
+__host__ __device__ constexpr uint32_t sched_stack_depth(int meshloc, bool small_scene) {
+    return meshloc == MESH_GLOBAL ? 10u : (small_scene ? 0u : (meshloc == MESH_NONE ? 7u : 3u));
+}
 template <int MESHLOC, bool LEAN, class Tab, class IO>
 __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& tab, const LdsMesh lds, const IO& io, uint32_t* work_head,
                                                 const uint32_t n_items, const uint32_t chunk_and_share, lds_u32* stage /* this wave's STAGE_WORDS */,
-                                                lds_u32* coop /* this wave's COOP_WORDS */, lds_u32* ostack /* this wave's 128 * sched_stack_depth(MESHLOC) words */) {
-    constexpr uint32_t SD = sched_stack_depth(MESHLOC);
+                                                lds_u32* coop /* this wave's COOP_WORDS */, lds_u32* ostack /* this wave's 128 * sched_stack_depth words */) {
+    constexpr uint32_t SD = sched_stack_depth(MESHLOC, Tab::small_scene);
     // mesh trees in global memory / object trees of scenes whose tables do not fit LDS can be walked nearer child first
     constexpr bool ORD_M = SD > 0u && MESHLOC == MESH_GLOBAL, ORD_T = SD > 0u && !Tab::small_scene;
     const bool ord_m = ORD_M && (S.ordered & ORD_MESH) != 0u, ord_t = ORD_T && (S.ordered & ORD_TREE) != 0u;   // wave-uniform
@@ -667,13 +676,11 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             };
             auto load_tri = [&](const Pair& P, float4& q0, float4& q1, float4& q2) {
                 if (P.in_lds) {
-                    lds_float4* tp = lds.tris + 3 * P.k;
-                    q0 = lds_load4(tp); q1 = lds_load4(tp + 1);
-                    // only ac.z of the third quad is needed (the rest are vertex ids for the shade stage)
-                    q2 = make_float4(((__attribute__((address_space(3))) const float*)tp)[8], 0.f, 0.f, 0.f);
+                    q0 = lds_load4(lds.tris + P.k); q1 = lds_load4(lds.tris1 + P.k);
+                    q2 = make_float4(lds.trisz[P.k], 0.f, 0.f, 0.f);
                     if (RTAMD_LDS_DUP & 2) {
-                        lds_dup4(tp); lds_dup4(tp + 1);
-                        const float z = ((volatile __attribute__((address_space(3))) const float*)tp)[8];
+                        lds_dup4(lds.tris + P.k); lds_dup4(lds.tris1 + P.k);
+                        const float z = ((volatile __attribute__((address_space(3))) const float*)lds.trisz)[P.k];
                         asm volatile("" ::"v"(z));
                     }
                 } else {

@@ -102,3 +102,16 @@ def test_ordered_tree_walk_spheres(rt, ol, sky):
     assert hits > 50_000
     for cap, (differ, spurious, near) in counts.items():
         assert spurious == 0 and differ <= 30, (cap, differ, spurious, near)  # near ties where spheres intersect
+
+
+def test_ordered_tree_walk_instanced_grid(rt, ol, sky):
+    """52 900 instances of the LDS-staged bunny in one AABBTree<Object>: the object tree walked nearer child first with the
+    three stack entries per lane that fit beside the mesh, the mesh itself in the reference's order."""
+    cam = (640, 480)
+    gpu = rt.Scene.grid(230, 230, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.grid(230, 230, sky=sky, cam=cam)
+    rays = np.ascontiguousarray(np.concatenate([ray_mix(160_000, 61, 430.0, (-1.0, 4.0)), cpu.primary_rays(0, 0, cam[0], cam[1])[:, ::4]], axis=1))
+    counts, hits = run(rt, gpu, cpu, rays, object_tree=True)
+    assert hits > 40_000
+    for cap, (differ, spurious, near) in counts.items():
+        assert differ <= 8, (cap, differ, spurious, near)

@@ -44,6 +44,7 @@ def main():
     sky = rt.load_skybox(max_width=512)
     g = args.grid
     makers = {
+        "grid": lambda: ("instanced grid 230x230", rt.Scene.grid(230, 230, sky=sky, cam=(640, 480)), 430.0, (-1.0, 4.0)),
         "merged": lambda: (f"merged grid {g}x{g}", rt.Scene.grid(g, g, sky=sky, cam=(640, 480), flat=3), 1.9 * g, (-1.0, 4.0)),
         "flat": lambda: (f"flattened grid {g}x{g}", rt.Scene.grid(g, g, sky=sky, cam=(640, 480), flat=1), 1.9 * g, (-1.0, 4.0)),
         "spheres": lambda: ("10 000 spheres", rt.Scene.spheres(n=10000, seed=1, sky=sky, cam=(640, 480)), 40.0, (0.0, 6.0)),
