@@ -333,9 +333,10 @@ enum rtamd_option {
                                      spurious t = 0 hit described under RTAMD_OPT_TREE_DEEPENING, and, in object trees only, two objects
                                      hit within one rounding step of each other in a different object's scale (the reference compares
                                      each object's t in that object's own space, so the winner can depend on which is tested first) */
-    RTAMD_OPT_ORDERED_STACK = 14, /* entries (0..15, default 15 = all the kernel holds: 10 for mesh trees in global memory, 7 in scenes
-                                     without meshes) of the per-lane stack an ordered walk may use; where it is full, the subtree at hand is
-                                     walked in the reference's order.  Same hits at any value (a test knob) */
+    RTAMD_OPT_ORDERED_STACK = 14, /* entries (0..15, default 15 = all the kernel holds: 10 for mesh trees in global memory, for object
+                                     trees 8 beside them, 14 in scenes without meshes, 6 beside a mesh staged in LDS) of the per-lane stack
+                                     an ordered walk may use; where it is full, the subtree at hand is walked in the reference's order.
+                                     Same hits at any value (a test knob) */
     RTAMD_OPT_STRICT_ORDER = 13   /* 1: RTAMD_OPT_TREE_DEEPENING = 0 and RTAMD_OPT_ORDERED_WALK = 0 in one call: every entry point visits
                                      nodes, objects and triangles in the reference's order, with no excepted ray; 0: both back to their
                                      defaults */

@@ -532,7 +532,7 @@ int rtamd_upload_scene(rtamd_context* ctx, const rtamd_scene_desc* sc) {
         // A walk that visits the nearer child first reports what the reference's does as long as a primitive's answer does not
         // depend on the t_max it is asked with beyond `t <= t_max`; a cuboid that holds the ray's origin answers its far side even
         // beyond t_max (cuboid.rs:22-28), so a tree with cuboids keeps the reference's order.
-        bool orderable = tr.n_nodes >= 65u;
+        bool orderable = tr.n_nodes >= 65u && tr.n_nodes <= (1u << 17);   // (the compact stack entries hold 17 bits of node index)
         for (uint32_t k = 0; k < tr.n_objects && orderable; k++) {
             const uint32_t g = sc->objects[tr.first_object + k].geom_kind;
             orderable = g == RTAMD_GEOM_MESH || g == RTAMD_GEOM_UNIT_SPHERE || g == RTAMD_GEOM_TRIANGLE;

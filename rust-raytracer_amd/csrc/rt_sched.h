@@ -316,15 +316,37 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t NI_ROOT = 0x7FFFFFFFu;
 // The next postponed child that still passes `t0 <= t_max + 0.01` (the one part of the visit test that depends on t_max).
+// COMPACT: 4-byte entries, for object trees in instances that have little LDS for the stack: {leaf: 1 bit, node index: 17 bits,
+// t0 rounded towards minus infinity to sign + exponent + 5 mantissa bits: 14 bits}, entry e of lane l at word 64 e + l.  The
+// rounded t0 is never above the exact one, so an entry is never dropped that the exact test would keep; one that is kept within
+// the 3 % of the rounding is turned away by the exact tests of the next step.  Trees of up to ORD_COMPACT_MAX_NODES nodes.
+static constexpr uint32_t ORD_COMPACT_MAX_NODES = 1u << 17;
+__device__ __forceinline__ uint32_t ordered_pack(uint32_t leaf_and_index, float t0) {
+    const uint32_t b = __float_as_uint(t0);
+    uint32_t q = b >> 18;
+    q += ((b >> 31) != 0u && (b & 0x3FFFFu) != 0u) ? 1u : 0u;   // negative: a larger magnitude is further down
+    return ((leaf_and_index >> 31) << 31) | ((leaf_and_index & 0x1FFFFu) << 14) | (q & 0x3FFFu);
+}
+template <bool COMPACT>
+__device__ __forceinline__ void ordered_push(lds_u32* slot0, uint32_t sp, uint32_t leaf_and_index, float t0) {
+    if (COMPACT) slot0[64u * sp] = ordered_pack(leaf_and_index, t0);
+    else *(lds_u64*)(slot0 + 128u * sp) = ((unsigned long long)__float_as_uint(t0) << 32) | leaf_and_index;
+}
+template <bool COMPACT>
 __device__ __forceinline__ bool ordered_pop(uint32_t& ni, uint32_t& sp, lds_u32* slot0, const float tmax) {
     while (sp > 0u) {
         sp--;
-        const unsigned long long e = *(lds_u64*)(slot0 + 128u * sp);
-        if (__uint_as_float((uint32_t)(e >> 32)) <= tmax + 0.01f) { ni = (uint32_t)e; return true; }
+        if (COMPACT) {
+            const uint32_t e = slot0[64u * sp];
+            if (__uint_as_float((e & 0x3FFFu) << 18) <= tmax + 0.01f) { ni = (e & LEAF_BIT) | ((e >> 14) & 0x1FFFFu); return true; }
+        } else {
+            const unsigned long long e = *(lds_u64*)(slot0 + 128u * sp);
+            if (__uint_as_float((uint32_t)(e >> 32)) <= tmax + 0.01f) { ni = (uint32_t)e; return true; }
+        }
     }
     return false;
 }
-template <bool EXACT>
+template <bool EXACT, bool COMPACT = false>
 __device__ __forceinline__ void ordered_step(const float4* nodes, const float4* wide, const f3 pos, const f3 inv, const float tmax, uint32_t& ni, uint32_t& nend,
                                              uint32_t& sp, const uint32_t sp_cap, bool& range, lds_u32* slot0 /* word 0 of this lane's entry 0 */, bool& leaf,
                                              uint32_t& first, uint32_t& end, bool& done) {
@@ -348,10 +370,15 @@ __device__ __forceinline__ void ordered_step(const float4* nodes, const float4* 
         const uint32_t next2 = enter2 ? ni + 1u : ((pass2 || leaf2) ? ni + 2u : A2);
         ni = enter1 ? ni : (on ? next2 : next1);
         if (enter1 || enter2) { leaf = true; first = enter1 ? first1 : first2; end = enter1 ? B1 : B2; return; }
-        if (ni >= nend) { range = false; done = !ordered_pop(ni, sp, slot0, tmax); }
+        if (ni >= nend) { range = false; done = !ordered_pop<COMPACT>(ni, sp, slot0, tmax); }
         return;
     }
-    if (popped_leaf) { leaf = true; first = first1; end = B1; return; }   // (its box passed when it was postponed and when it was popped)
+    // (its box passed when it was postponed and at the pop; a compact entry's rounded t0 lets a few through that the exact test now turns away)
+    if (popped_leaf) {
+        if (!COMPACT || pass1) { leaf = true; first = first1; end = B1; }
+        else done = !ordered_pop<COMPACT>(ni, sp, slot0, tmax);
+        return;
+    }
     if (at_root) {
         if (pass1 && leaf1 && first1 < B1) { leaf = true; first = first1; end = B1; return; }
         if (!pass1 || leaf1) { done = true; return; }
@@ -369,8 +396,7 @@ __device__ __forceinline__ void ordered_step(const float4* nodes, const float4* 
     }
     const bool right_first = both ? t02 < t01 : hit_r;   // equal: the left child, as the reference
     if (both) {
-        const uint32_t w0 = right_first ? ((leaf1 ? LEAF_BIT : 0u) | l_idx) : ((leaf2 ? LEAF_BIT : 0u) | r_idx);
-        *(lds_u64*)(slot0 + 128u * sp) = ((unsigned long long)__float_as_uint(right_first ? t01 : t02) << 32) | w0;
+        ordered_push<COMPACT>(slot0, sp, right_first ? ((leaf1 ? LEAF_BIT : 0u) | l_idx) : ((leaf2 ? LEAF_BIT : 0u) | r_idx), right_first ? t01 : t02);
         sp++;
     }
     if (hit_l || hit_r) {
@@ -378,17 +404,18 @@ __device__ __forceinline__ void ordered_step(const float4* nodes, const float4* 
         leaf = n_leaf; first = right_first ? first2 : first1; end = right_first ? B2 : B1;
         ni = right_first ? r_idx : l_idx;
     } else {
-        done = !ordered_pop(ni, sp, slot0, tmax);
+        done = !ordered_pop<COMPACT>(ni, sp, slot0, tmax);
     }
 }
 // The leaf handed out by ordered_step is done (tmax: the ray's t_max now).  True: nothing is left of the walk.
+template <bool COMPACT = false>
 __device__ __forceinline__ bool ordered_leaf_done(uint32_t& ni, const uint32_t nend, uint32_t& sp, bool& range, lds_u32* slot0, const float tmax) {
     if (range) {
         ni++;
         if (ni < nend) return false;
         range = false;
     }
-    return !ordered_pop(ni, sp, slot0, tmax);
+    return !ordered_pop<COMPACT>(ni, sp, slot0, tmax);
 }
 
 // The lean form of a scheduler kernel serves scenes that hold nothing but what most scenes hold: meshes and cuboids under
@@ -412,7 +439,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     constexpr bool ORD_M = SD > 0u && MESHLOC == MESH_GLOBAL, ORD_T = SD > 0u && !Tab::small_scene;
     const bool ord_m = ORD_M && (S.ordered & ORD_MESH) != 0u, ord_t = ORD_T && (S.ordered & ORD_TREE) != 0u;   // wave-uniform
     // the object tree leaves two entries to the mesh walks inside it
-    constexpr uint32_t SD_T = ORD_M ? (SD > 2u ? SD - 2u : 0u) : SD;
+    // (alone in the area -- no mesh walks on the stack -- the tree's entries are the compact ones: twice as many)
+    constexpr bool TC = !ORD_M;
+    constexpr uint32_t SD_T = ORD_M ? (SD > 2u ? SD - 2u : 0u) : (2u * SD < 15u ? 2u * SD : 15u);
     const uint32_t cap_m = SD < S.ordered_cap ? SD : S.ordered_cap, cap_t = SD_T < S.ordered_cap ? SD_T : S.ordered_cap;   // wave-uniform
     const uint32_t chunk = chunk_and_share & 0xFFFFu, share8 = (chunk_and_share >> 16) & 0xFu;
     const uint32_t lane = lane_id();
@@ -835,7 +864,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 uint32_t spt = (fl >> SPT_SHIFT) & SP_MASK;
                 bool range = (fl & F_TRANGE) != 0u, leaf, done;
                 uint32_t first = 0u, end = 0u;
-                ordered_step<EXACT>(S.nodes + 2 * (size_t)t_base, S.wide + 4 * (size_t)t_base, wpos, winv, wtmax, t_i, t_n, spt, cap_t, range, ostack + 2u * lane,
+                ordered_step<EXACT, TC>(S.nodes + 2 * (size_t)t_base, S.wide + 4 * (size_t)t_base, wpos, winv, wtmax, t_i, t_n, spt, cap_t, range, ostack + (TC ? lane : 2u * lane),
                                     leaf, first, end, done);
                 fl = (fl & ~(F_TRANGE | (SP_MASK << SPT_SHIFT))) | (range ? F_TRANGE : 0u) | (spt << SPT_SHIFT);
                 o_cur = leaf ? t_first + first : o_cur; o_end = leaf ? t_first + end : o_end;
@@ -918,7 +947,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     if (ORD_T && (fl & F_TORD)) {   // leaf of an ordered walk finished
                         bool range = (fl & F_TRANGE) != 0u;
                         uint32_t spt = (fl >> SPT_SHIFT) & SP_MASK;
-                        const bool tree_done = ordered_leaf_done(t_i, t_n, spt, range, ostack + 2u * lane, wtmax);
+                        const bool tree_done = ordered_leaf_done<TC>(t_i, t_n, spt, range, ostack + (TC ? lane : 2u * lane), wtmax);
                         fl = (fl & ~(F_TRANGE | (SP_MASK << SPT_SHIFT))) | (range ? F_TRANGE : 0u) | (spt << SPT_SHIFT);
                         if (tree_done) fl &= ~(F_INTREE | F_TORD); else st = ST_TNODE;
                     } else if (fl & F_INTREE) {  // leaf of the object tree finished: i += 1

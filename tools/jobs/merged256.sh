@@ -1,0 +1,6 @@
+( while sleep 45; do date >> gpurun_out/heartbeat.txt; done ) &
+HB=$!
+bash tools/collect_profiles.sh r3a_grid_merged --workload bunny_grid_merged_230x230_7680x4320_256spp_depth5 --steps 1 --warmup 0 > gpurun_out/cp_merged.log 2>&1
+RC=$?
+kill $HB
+exit $RC
