@@ -106,3 +106,33 @@ def test_walk_in_passes_differs_only_by_spurious_hits(rt, sky):
         assert not np.any(occ_differ & ~((occ_single == 1) & (occ_passes == 0)))   # a spurious hit occludes at any t_max
         total += int(differ.sum()) + int(occ_differ.sum())
     assert total <= 12, total
+
+
+def test_walk_in_passes_with_ray_origins_inside_cuboids(rt, ol, sky):
+    """3 000 spheres and cuboids in one top-level tree (more than 256 nodes, walked in passes when asked to), rays that start
+    anywhere in the scene's volume, thousands of them inside a cuboid: a cuboid that holds the origin answers its far side
+    even beyond t_max (cuboid.rs:22-28), the one primitive whose answer depends on the order of the walk.  The walk in
+    passes keeps the reference's order inside a pass, and this tree is not walked nearer child first (it holds cuboids):
+    bit for bit the oracle's hits, with the passes on and off."""
+    cam = (240, 180)
+    gpu = rt.Scene.scatter(3000, seed=5, accelerate=True, sky=sky, cam=cam).upload(0)
+    cpu = ol.OracleScene.scatter(3000, seed=5, accelerate=True, sky=sky, cam=cam)
+    # (3 000 objects: the list's top-level tree has thousands of nodes, far beyond the 257 from which a tree is walked in passes)
+    rng = np.random.default_rng(91)
+    n = 300_000
+    rays = random_rays(n, seed=92, center=(0, 0, 1), radius=9.0)
+    rays[0:3] = np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(0.0, 2.5, n)]).astype(np.float32)   # inside the objects' slab
+    rays = np.ascontiguousarray(rays)
+    ref = cpu.trace_closest(rays)
+    from test_gpu_trace import check_closest
+    for mode in (0, 2):
+        try:
+            gpu.set_option(rt.OPT_TREE_DEEPENING, mode)
+            gpu.set_option(rt.OPT_ORDERED_WALK, 2)
+            check_closest(rt, gpu.trace_closest(rays), ref, exact_uv=False)
+        finally:
+            gpu.set_option(rt.OPT_TREE_DEEPENING, 1)
+            gpu.set_option(rt.OPT_ORDERED_WALK, 1)
+    # rays that leave a cuboid through its far side: the hit lies behind the origin's own cuboid wall
+    inside = (ref["obj"] >= 0) & (ref["t"] > 0)
+    assert inside.sum() > 10_000
