@@ -30,6 +30,8 @@ struct rtamd_context {
     int ordered = 1;         // walks that visit the nearer child first (rt_sched.h): same three values
     uint32_t ordered_ok = 0; // ORD_MESH / ORD_TREE: the uploaded scene's trees allow them
     uint32_t ordered_cap = 15; // stack entries an ordered walk may use (RTAMD_OPT_ORDERED_STACK)
+    int frame_kernel = 0;    // RTAMD_OPT_FRAME_KERNEL
+    int frame_step_min = 64; // RTAMD_OPT_FRAME_STEP_MIN
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
@@ -419,6 +421,11 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
         case RTAMD_OPT_ORDERED_STACK:
             if (value < 0 || value > 15) return fail(ctx, RTAMD_E_INVALID, "ordered stack entries must be in [0, 15]");
             ctx->ordered_cap = (uint32_t)value; ctx->S.ordered_cap = ctx->ordered_cap;
+            return RTAMD_OK;
+        case RTAMD_OPT_FRAME_KERNEL: ctx->frame_kernel = value != 0 ? 1 : 0; return RTAMD_OK;
+        case RTAMD_OPT_FRAME_STEP_MIN:
+            if (value < 1 || value > 64) return fail(ctx, RTAMD_E_INVALID, "frame step threshold must be in [1, 64]");
+            ctx->frame_step_min = (int)value;
             return RTAMD_OK;
         case RTAMD_OPT_STRICT_ORDER:
             ctx->deepen = value != 0 ? 0 : 1; ctx->S.deepen = ctx->deepen >= 1 ? 1u : 0u;
@@ -1091,6 +1098,64 @@ int render_depth_first_rounds(rtamd_context* ctx, const rtamd_camera* cam, const
     timed_collect(ctx, stats);
     return RTAMD_OK;
 }
+
+// scatter_rays = 1 as one launch per chunk of 256 * waves pixel slots (rt_mega.hip).  RTAMD_E_UNSUPPORTED: the kernel instance the
+// scene needs is not built in this mode (the caller takes the pipeline).
+int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, size_t total_slots,
+                        uint32_t S_total, uint32_t S_shoot, float* out, rtamd_stats* stats) {
+    const size_t cap = (size_t)mega_waves(ctx->S, ctx->cfg) * 256u;
+    if (ctx->ws.empty()) ctx->ws.resize(1);
+    rtamd_context::Workspace& ws = ctx->ws[0];
+    int rc = ensure_wave(ctx, ws, cap, S_total);
+    if (rc) return rc;
+    WaveBufs W = ws.W;
+    W.cap = (uint32_t)ws.cap;
+    hipStream_t st = ws.stream;
+    const MegaFrame F{make_region(*region), make_camera(*cam), (uint32_t)integ->antialiasing, integ->max_depth, integ->shadow_rays, S_shoot,
+                      (uint32_t)ctx->frame_step_min, out};
+    hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
+    HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ev0, 0));
+    HIP_TRY(ctx, hipMemsetAsync(W.stats, 0, 32, st));
+    uint64_t launches = 0;
+    for (size_t begin = 0; begin < total_slots; begin += cap) {
+        const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
+        timed_begin(ctx, 0, st);
+        const hipError_t e = launch_mega(ctx->S, ctx->cfg, W, F, (uint32_t)begin, chunk_n, st);
+        timed_end(ctx, st);
+        if (e == hipErrorNotSupported && begin == 0) {
+            (void)hipStreamSynchronize(st);
+            ctx->event_pool.push_back(ev0);
+            ctx->event_pool.push_back(ev1);
+            ctx->timed.clear();
+            return RTAMD_E_UNSUPPORTED;
+        }
+        HIP_TRY(ctx, e);
+        launches += 2;
+    }
+    uint64_t hstats[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(hstats, W.stats, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(ws.done, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ws.done, 0));
+    HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    ctx->event_pool.push_back(ev0);
+    ctx->event_pool.push_back(ev1);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->closest_rays = hstats[0];
+        stats->any_rays = hstats[1];
+        stats->paths = owned_pixels(*region) * (uint64_t)integ->antialiasing * integ->antialiasing;
+        stats->launches = launches;
+        stats->device_ms = ms;
+    }
+    timed_collect(ctx, stats);
+    // (1: a wave gave up after its step limit, 2: a wave ended with pixels unfinished, 3 / 4: a pixel or hit record out of range)
+    if (hstats[2] != 0) return fail(ctx, RTAMD_E_DEVICE, ("frame kernel: internal error " + std::to_string(hstats[2])).c_str());
+    return RTAMD_OK;
+}
 }  // namespace
 
 size_t rtamd_region_pixels(const rtamd_region* region) {
@@ -1125,6 +1190,10 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
         // the one-lane-per-pixel kernel
         if (ctx->df_rounds && integ->max_depth >= 1) return render_depth_first_rounds(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
         return render_depth_first(ctx, cam, integ, region, total_slots, out, stats);
+    }
+    if (ctx->frame_kernel && integ->max_depth >= 1 && S_shoot <= 7) {
+        const int rc = render_frame_kernel(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
+        if (rc != RTAMD_E_UNSUPPORTED) return rc;
     }
     // pixel groups: at most n_streams in flight, none smaller than 64 Ki pixels unless the region is
     const size_t G = (size_t)ctx->n_streams;

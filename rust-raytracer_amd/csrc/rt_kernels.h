@@ -170,6 +170,20 @@ struct DfFrame {
 hipError_t launch_df_begin(const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t out_base, hipStream_t st);
 hipError_t launch_df_step(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t cur, uint32_t in_base,
                           uint32_t out_base, uint32_t zero_base, size_t upper, hipStream_t st);
+// The integrator of scatter_rays = 1 as one launch per chunk (rt_mega.hip): every wave owns up to 256 pixels from their first camera ray
+// to their last sample.  A launch takes at most 256 * mega_waves() pixel slots; n_shoot (shadow rays per lit hit) at most 7,
+// max_depth at least 1.  Uses the per-slot arrays of W (capacity at least 256 * mega_waves()).
+struct MegaFrame {
+    RegionDev R;
+    CameraDev cam;
+    uint32_t aa;
+    int32_t max_depth, shadow_rays;
+    uint32_t n_shoot;
+    uint32_t step_min;   // resumable pixels of a wave from which its integrator step runs without waiting for idle lanes (1..64)
+    float* out;
+};
+uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg);
+hipError_t launch_mega(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, hipStream_t st);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 // The reference's binned-SAH tree over n boxes (6 floats each, device memory), built on the GPU (rt_bvh.hip).
 // nodes_out: room for 2 n records; *n_nodes_out includes the sentinel; order_out: n primitive indices in tree order.

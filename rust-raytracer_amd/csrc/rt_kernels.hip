@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <vector>
 #include "rt_sched.h"
+#include "rt_stage.h"
+#include "rt_integrate.h"
 
 namespace rtamd {
 
@@ -24,8 +26,6 @@ struct LdsMem {
         q0 = tris[3 * k]; q1 = tris[3 * k + 1]; q2 = tris[3 * k + 2];
     }
 };
-
-extern __shared__ float4 g_lds[];
 
 template <bool USE_LDS>
 __device__ __forceinline__ const LdsMem* stage_mesh(const DevScene& S, LdsMem& mem) {
@@ -82,128 +82,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene S, RayBatch 
 }
 
 // Scheduler versions of the two batch kernels (see rt_sched.h).
-// Stages the LDS-resident parts of the scene for a scheduler kernel: the small mesh (MESHLOC != GLOBAL) followed by the
-// scene tables.  LDS layout, in float4 units:
-//   TAB_LDS: [mesh nodes | mesh triangles | objects (8 each) | ops (3 each) | cuboids (3 each) | root items (uint2)]
-//   TAB_MID: [mesh nodes | mesh triangles | classes (8 each) | cuboids (3 each) | tree headers (uint4) | root items (uint2)]
-enum : int { TAB_GLOBAL = 0, TAB_LDS = 1, TAB_MID = 2 };
-// Block-wide copy global -> LDS in two halves, so that the loads of several tables are all in flight before the first
-// store waits for one: `begin` issues up to D loads per thread, `end` stores them (and copies whatever lies beyond D
-// elements per thread one by one).  A trace launch starts with this copy in every block; as one load and one store per
-// loop trip it was a chain of a dozen memory round trips.
-template <int D, class T>
-__device__ __forceinline__ void block_copy_begin(T (&v)[D], const T* src, uint32_t n) {
-    if (n == 0u) {   // (nothing to read: src may be null)
-#pragma unroll
-        for (int k = 0; k < D; k++) v[k] = T{};
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        // (threads past the end re-read element 0: an unconditional load keeps v in registers)
-        const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
-        v[k] = src[i < n ? i : 0u];
-    }
-}
-template <int D, class T>
-__device__ __forceinline__ void block_copy_end(const T (&v)[D], T* dst, const T* src, uint32_t n) {
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
-        if (i < n) dst[i] = v[k];
-    }
-    for (uint32_t i = threadIdx.x + (uint32_t)D * blockDim.x; i < n; i += blockDim.x) dst[i] = src[i];
-}
-
-__device__ __forceinline__ uint32_t n_node4_of(const DevScene& S) { return 2u * S.meshes[S.lds_mesh].n_nodes; }
-template <int MESHLOC, int TABKIND>
-__device__ __forceinline__ void stage_scene(const DevScene& S, LdsMesh& lds, LdsTab& ltab, MidTab& mtab) {
-    uint32_t base = 0;  // float4 offset
-    lds.nodes = (lds_float4*)g_lds;
-    lds.tris = (lds_float4*)g_lds;
-    lds.tris1 = (lds_float4*)g_lds;
-    lds.trisz = (__attribute__((address_space(3))) const float*)g_lds;
-    constexpr bool MESH = MESHLOC == MESH_LDS || MESHLOC == MESH_MIXED;
-    uint32_t n_tris = 0;
-    // the staged mesh's triangles go to three planes (see LdsMesh): quad c of triangle k lands in plane c
-    auto store_tris = [&](const float4 (&v)[8], const float4* src, uint32_t n4) {
-        float4* q0 = g_lds + n_node4_of(S);
-        float4* q1 = q0 + n_tris;
-        float* z = (float*)(q1 + n_tris);
-        auto put = [&](uint32_t i, const float4& q) {
-            const uint32_t k = i / 3u, c = i - 3u * k;
-            if (c == 0u) q0[k] = q; else if (c == 1u) q1[k] = q; else z[k] = q.x;
-        };
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
-            if (i < n4) put(i, v[k]);
-        }
-        for (uint32_t i = threadIdx.x + 8u * blockDim.x; i < n4; i += blockDim.x) put(i, src[i]);
-    };
-    float4 vn[2], vt[8], va[1], vb[1], vc[1];
-    uint32_t n_node4 = 0, n_tri4 = 0;
-    const float4 *gn = nullptr, *gt = nullptr;
-    if (MESH) {
-        const DevMesh m = S.meshes[S.lds_mesh];
-        n_node4 = 2 * m.n_nodes;
-        n_tri4 = S.lds_bytes / 16 - n_node4;   // (lds_bytes: the mesh as 32-byte nodes + 48-byte triangles, as global memory holds it)
-        n_tris = n_tri4 / 3u;
-        gn = S.nodes + 2 * (size_t)m.node_base;
-        gt = S.tris + 3 * (size_t)m.tri_base;
-        block_copy_begin(vn, gn, n_node4);
-        block_copy_begin(vt, gt, n_tri4);
-        lds.tris = (lds_float4*)g_lds + n_node4;
-        lds.tris1 = lds.tris + n_tris;
-        lds.trisz = (__attribute__((address_space(3))) const float*)(lds.tris1 + n_tris);
-        base = lds_mesh_bytes(m.n_nodes, n_tris) / 16u;
-    }
-    if (TABKIND == TAB_LDS) {
-        const uint32_t n_obj4 = 8 * S.n_objects, n_op4 = 3 * S.n_ops, n_cub4 = 3 * S.n_cuboids;
-        const float4* go = (const float4*)S.objects;
-        const float4* gp = (const float4*)S.ops;
-        const float4* gc = (const float4*)S.cuboids;
-        block_copy_begin(va, go, n_obj4);
-        block_copy_begin(vb, gp, n_op4);
-        block_copy_begin(vc, gc, n_cub4);
-        uint2* lr = (uint2*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
-        for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
-        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); store_tris(vt, gt, n_tri4); }
-        block_copy_end(va, g_lds + base, go, n_obj4);
-        block_copy_end(vb, g_lds + base + n_obj4, gp, n_op4);
-        block_copy_end(vc, g_lds + base + n_obj4 + n_op4, gc, n_cub4);
-        ltab.S = &S;
-        ltab.objects = (lds_float4*)g_lds + base;
-        ltab.ops = (lds_float4*)g_lds + base + n_obj4;
-        ltab.cuboids = (lds_float4*)g_lds + base + n_obj4 + n_op4;
-        ltab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_obj4 + n_op4 + n_cub4);
-    } else if (TABKIND == TAB_MID) {
-        const uint32_t n_cls4 = 8 * S.n_classes, n_cub4 = 3 * S.n_cuboids, n_tree4 = S.n_trees;
-        const float4* gk = (const float4*)S.classes;
-        const float4* gc = (const float4*)S.cuboids;
-        const float4* gh = (const float4*)S.trees;
-        block_copy_begin(va, gk, n_cls4);
-        block_copy_begin(vb, gc, n_cub4);
-        block_copy_begin(vc, gh, n_tree4);
-        uint2* lr = (uint2*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
-        for (uint32_t i = threadIdx.x; i < S.n_root; i += blockDim.x) lr[i] = make_uint2(S.root[i].kind, S.root[i].index);
-        if (MESH) { block_copy_end(vn, g_lds, gn, n_node4); store_tris(vt, gt, n_tri4); }
-        block_copy_end(va, g_lds + base, gk, n_cls4);
-        block_copy_end(vb, g_lds + base + n_cls4, gc, n_cub4);
-        block_copy_end(vc, g_lds + base + n_cls4 + n_cub4, gh, n_tree4);
-        mtab.S = &S;
-        mtab.classes = (lds_float4*)g_lds + base;
-        mtab.cuboids = (lds_float4*)g_lds + base + n_cls4;
-        mtab.trees = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4);
-        mtab.roots = (__attribute__((address_space(3))) const uint32_t*)(g_lds + base + n_cls4 + n_cub4 + n_tree4);
-    } else if (MESH) {
-        block_copy_end(vn, g_lds, gn, n_node4);
-        store_tris(vt, gt, n_tri4);
-    }
-    if (MESH || TABKIND != TAB_GLOBAL) __syncthreads();
-}
 
 struct BatchIO {
+    static constexpr bool MEGA = false;
     DevScene S;
     RayBatch rays;
     HitBatch hits;
@@ -257,223 +138,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, work_head, n, chunk, stage, coop, ostack);
 }
 
-// ------------------------------------------------------------------------------------------------
-// rand 0.6 SmallRng on 64-bit targets = PCG Mcg128Xsl64, seeded through rand_core's
-// seed_from_u64 (PCG32 expansion).  State is the 128-bit MCG state as two 64-bit halves.
-// ------------------------------------------------------------------------------------------------
-struct Rng { uint64_t lo, hi; };
-__device__ __forceinline__ Rng rng_seed(uint64_t state) {
-    const uint64_t MUL = 6364136223846793005ULL, INC = 11634580027462260723ULL;
-    uint32_t w[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        state = state * MUL + INC;
-        uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
-        uint32_t rot = (uint32_t)(state >> 59);
-        w[k] = (xs >> rot) | (xs << ((32 - rot) & 31));
-    }
-    Rng r;
-    r.lo = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) | 1ULL;
-    r.hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-    return r;
-}
-__device__ __forceinline__ uint32_t rng_u32(Rng& r) {
-    const uint64_t MH = 0x2360ED051FC65DA4ULL, ML = 0x4385DF649FCCF645ULL;
-    uint64_t lo = r.lo * ML;
-    uint64_t hi = __umul64hi(r.lo, ML) + r.lo * MH + r.hi * ML;
-    r.lo = lo; r.hi = hi;
-    uint32_t rot = (uint32_t)(hi >> 58);
-    uint64_t xsl = hi ^ lo;
-    uint64_t o = (xsl >> rot) | (xsl << ((64 - rot) & 63));
-    return (uint32_t)o;
-}
-__device__ __forceinline__ float rng_f32(Rng& r) {  // Standard: 24 bits * 2^-24
-    return (1.0f / 16777216.0f) * (float)(rng_u32(r) >> 8);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Shading helpers (src/material.rs, src/light.rs, src/scene.rs:16-21, src/texture.rs:70-82).
-// ------------------------------------------------------------------------------------------------
-static constexpr float PI_F = 3.14159274101257324219f;
-
-__device__ __forceinline__ float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
-__device__ __forceinline__ float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
-
-// Image::color_at, src/texture.rs:70-82: nearest texel, clamped.
-__device__ __forceinline__ f3 image_texel(const DevScene& S, uint32_t first, uint32_t w, uint32_t h, float u, float v) {
-    float fw = (float)w, fh = (float)h;
-    float fx = rust_max(rust_min(u * fw, fw - 1.0f), 0.0f);
-    float fy = rust_max(rust_min(v * fh, fh - 1.0f), 0.0f);
-    uint32_t x = (uint32_t)fx, y = (uint32_t)fy;
-    uint32_t p = S.sky[first + (size_t)y * w + x];
-    return mk((float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f, (float)((p >> 16) & 0xFFu) / 255.0f);
-}
-__device__ __forceinline__ f3 sky_color(const DevScene& S, f3 d) {   // scene.rs:16-21
-    float u = atan2f(d.x, d.y) / PI_F * 0.5f + 0.5f;
-    float v = acosf(d.z) / PI_F;
-    return image_texel(S, 0u, S.sky_w, S.sky_h, u, v);
-}
-__device__ __forceinline__ int32_t sat_i32(float x) {  // `as i32`: saturating, NaN -> 0
-    if (!(x == x)) return 0;
-    if (x >= 2147483648.0f) return 2147483647;
-    if (x <= -2147483648.0f) return -2147483647 - 1;
-    return (int32_t)x;
-}
-__device__ __forceinline__ f3 texture_color(const DevScene& S, const DevMaterial& m, float u, float v) {
-    if (m.tex_kind == TEX_UV) return mk(u, v, 0.0f);                 // texture.rs:22-26
-    if (m.tex_kind == TEX_CHECKERBOARD) {                             // texture.rs:36-47
-        const int32_t i = sat_i32(u * (float)m.tex_param);
-        const int32_t j = sat_i32(v * (float)m.tex_param);
-        return ((i % 2 == 0) != (j % 2 == 0)) ? mk(0.f, 0.f, 0.f) : mk(1.f, 1.f, 1.f);
-    }
-    if (m.tex_kind == TEX_IMAGE) {
-        const DevImage im = S.images[m.tex_param];
-        return image_texel(S, im.first, im.w, im.h, u, v);
-    }
-    return mk(m.color[0], m.color[1], m.color[2]);                    // texture.rs:14-18
-}
-
-__device__ __forceinline__ f3 reflection(f3 n, f3 i) { return i - (2.0f * n) * dot(n, i); }  // material.rs:83-85
-__device__ __forceinline__ bool refraction(f3 normal, f3 i, float ior, f3& o) {             // material.rs:87-101
-    float side = dot(normal, i);
-    float cosi, eta;
-    f3 n;
-    if (side < 0.0f) { cosi = -side; eta = 1.0f / ior; n = normal; }
-    else { cosi = side; eta = ior; n = -normal; }
-    float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
-    if (k > 0.0f) {
-        o = eta * i + (eta * cosi - sqrtf(k)) * n;
-        return true;
-    }
-    return false;
-}
-__device__ __forceinline__ float fresnel(f3 normal, f3 i, float ior) {                      // material.rs:103-121
-    float side = dot(normal, i);
-    float cosi, etat, etai;
-    if (side < 0.0f) { cosi = -side; etat = ior; etai = 1.0f; }
-    else { cosi = side; etat = 1.0f; etai = ior; }
-    float sint = etai / etat * sqrtf(1.0f - cosi * cosi);
-    if (sint < 1.0f) {
-        float cost = sqrtf(1.0f - sint * sint);
-        float rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
-        float rp = ((etat * cosi) - (etai * cost)) / ((etai * cosi) + (etat * cost));
-        return (rs * rs + rp * rp) / 2.0f;
-    }
-    return 1.0f;
-}
-__device__ __forceinline__ f3 material_diffuse(const DevScene& S, const DevMaterial& m, float u, float v) {  // Material::sample_at
-    if (m.kind == MAT_NULL) return mk(0.f, 1.f, 0.f);
-    if (m.kind == MAT_LAMBERT) return texture_color(S, m, u, v);
-    if (m.kind == MAT_GLOSSY) return texture_color(S, m, u, v) * (1.0f - m.p1);
-    return mk(0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ bool material_scatter(const DevMaterial& m, f3 n, f3 i, Rng& rng, f3& out_dir, f3& w) {
-    if (m.kind == MAT_METAL) {  // material.rs:32-35
-        out_dir = i - (2.0f * n) * dot(n, i);
-        w = fill(1.0f);
-        return true;
-    }
-    if (m.kind == MAT_GLOSSY) {  // material.rs:45-69 (accept test reads the mirror direction)
-        f3 out = reflection(n, i);
-        f3 a, b;
-        ortho_axes(out, a, b);
-        float side = dot(n, i) < 0.0f ? 1.0f : -1.0f;
-        for (int k = 0; k < 10; k++) {
-            float theta = rng_f32(rng) * 2.0f * PI_F;
-            float u = rng_f32(rng);
-            float p = powf(u, 2.0f / (1.0f + m.p0));
-            float r = sqrtf(1.0f - p);
-            float x = r * cosf(theta);
-            float y = r * sinf(theta);
-            float z = sqrtf(p);
-            f3 o = (x * a + y * b) + z * out;
-            if (dot(n, out) * side > 0.0f) {
-                out_dir = o;
-                w = fill(1.0f) * m.p1;
-                return true;
-            }
-        }
-        return false;
-    }
-    if (m.kind == MAT_TRANSPARENT) {  // material.rs:123-133
-        f3 o;
-        if (rng_f32(rng) < fresnel(n, i, m.p0)) {
-            o = reflection(n, i);
-        } else if (!refraction(n, i, m.p0, o)) {
-            return false;
-        }
-        out_dir = o;
-        w = fill(1.0f);
-        return true;
-    }
-    return false;
-}
-__device__ __forceinline__ bool light_is_delta(const DevLight& l) {  // light.rs:29-31,76-78,125-127
-    if (l.kind == LIGHT_AMBIENT) return true;
-    if (l.kind == LIGHT_POINT) return l.param == 0.0f;
-    if (l.kind == LIGHT_DIRECTION) return l.param > 0.0f;
-    return false;
-}
-__device__ __forceinline__ void light_sample(const DevLight& l, f3 pos, f3 normal, Rng& rng, f3& dir, float& t_max, f3& ill) {
-    f3 E = mk(l.emission[0], l.emission[1], l.emission[2]);
-    if (l.kind == LIGHT_AMBIENT) {  // light.rs:24-27
-        dir = normal; t_max = 0.0f; ill = E;
-    } else if (l.kind == LIGHT_POINT) {  // light.rs:50-74
-        // rejection-sample a point of the unit ball; gen_range(-1, 1) draws a float in [1, 2) from the top 23 bits of a
-        // u32, maps it with value * scale + (low - scale), and redraws a result that rounds up to the high end
-        f3 fv;
-        for (;;) {
-            float f[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                for (;;) {
-                    const float v12 = __uint_as_float((rng_u32(rng) >> 9) | 0x3F800000u);
-                    const float scale = 1.0f - (-1.0f);
-                    const float res = v12 * scale + (-1.0f - scale);
-                    if (res < 1.0f) { f[k] = res; break; }
-                }
-            }
-            fv = mk(f[0], f[1], f[2]);
-            if (dot(fv, fv) < 1.0f) break;
-        }
-        const f3 offset = (mk(l.vec[0], l.vec[1], l.vec[2]) + fv * l.param) - pos;
-        const float dist_sq = dot(offset, offset);
-        const float dist = sqrtf(dist_sq);
-        dir = offset / dist;
-        const float c = rust_max(dot(dir, normal), 0.0f);
-        t_max = dist; ill = (E / dist_sq) * c;
-    } else if (l.kind == LIGHT_DIRECTION) {  // light.rs:97-123
-        f3 ld = mk(l.vec[0], l.vec[1], l.vec[2]);
-        f3 o;
-        if (l.param > 0.0f) {
-            float theta = rng_f32(rng) * 2.0f * PI_F;
-            float u = rng_f32(rng);
-            float p = powf(u, l.param);
-            float r = sqrtf(1.0f - p);
-            float x = r * cosf(theta);
-            float y = r * sinf(theta);
-            float z = sqrtf(p);
-            f3 a, b;
-            ortho_axes(ld, a, b);
-            o = (x * a + y * b) - z * ld;
-        } else {
-            o = -ld;
-        }
-        float c = rust_max(dot(o, normal), 0.0f);
-        dir = o; t_max = 1e12f; ill = E * c;
-    } else {  // LIGHT_AO, light.rs:144-158
-        float theta = rng_f32(rng) * 2.0f * PI_F;
-        float u = rng_f32(rng);
-        float r = sqrtf(u);
-        float x = r * cosf(theta);
-        float y = r * sinf(theta);
-        float z = sqrtf(1.0f - u);
-        f3 a, b;
-        ortho_axes(normal, a, b);
-        dir = (a * x + b * y) + normal * z;
-        t_max = l.param; ill = E;
-    }
-}
 
 // Diagnostic build only: time stamps (s_memtime, 100 MHz) along the shade kernel's dependency chain, taken by the
 // first thread of the first block; slot k accumulates the ticks between probe k-1 and probe k, slot 16 + k counts.
@@ -553,36 +217,6 @@ __device__ __forceinline__ uint32_t block_append_range(bool take, uint32_t* coun
     return sh[wave] + before;
 }
 
-// Whether a sample of the light can need a shadow ray at all (illumination() skips the occlusion test where the
-// light's t_max is 0, integrator.rs:124): an ambient light never does, an occlusion light of reach 0 neither.
-__device__ __forceinline__ bool light_shoots(const DevLight& l) {
-    if (l.kind == LIGHT_AMBIENT) return false;
-    if (l.kind == LIGHT_AO) return !(l.param == 0.0f);
-    return true;
-}
-
-// Pixel slot -> pixel coordinates of the owned tile set (see rtamd_region).
-__device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, uint32_t& cx, uint32_t& cy) {
-    uint32_t per_tile = R.tile_w * R.tile_h;
-    uint32_t q = slot / per_tile, r = slot - q * per_tile;
-    uint32_t ty = r / R.tile_w, tx = r - ty * R.tile_w;
-    uint32_t tile = R.tile_first + q * R.tile_stride;
-    uint32_t tyi = tile / R.tiles_x, txi = tile - tyi * R.tiles_x;
-    uint32_t px = txi * R.tile_w + tx, py = tyi * R.tile_h + ty;
-    cx = R.x0 + px; cy = R.y0 + py;
-    return px < R.w && py < R.h && tile < R.n_tiles;
-}
-
-// Direction of the camera ray through sample (si, sj) of pixel (cx, cy): integrator.rs:41-42, scene.rs:84-90.
-__device__ __forceinline__ f3 primary_dir(const CameraDev& cam, uint32_t cx, uint32_t cy, uint32_t si, uint32_t sj, uint32_t aa) {
-    float n = (float)aa;
-    float x = (float)cx + ((float)si + 0.5f) / n - 0.5f;
-    float y = (float)cy + ((float)sj + 0.5f) / n - 0.5f;
-    float u = 2.0f * (x / (float)cam.width) - 1.0f;
-    float v = 2.0f * (y / (float)cam.height) - 1.0f;
-    f3 d = (cam.dir + u * cam.horizontal) + v * cam.vertical;
-    return normalize(d);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Stage 1: ray generation.  One lane per pixel slot of the chunk; sample (si, sj) of the regular
@@ -626,6 +260,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void k_raygen(WaveBufs W, RegionDev R,
 // left in the two shade sets.
 // ------------------------------------------------------------------------------------------------
 struct WaveIO {
+    static constexpr bool MEGA = false;
     const float* q_ray;   // closest-hit ray queue of this bounce -> h_rec
     const float* p_ray;   // primary rays -> p_rec
     const float *a_ray0, *a_ray1;   // shadow-ray queues of the two shade sets (separate members: an array would be indexed through scratch memory)
@@ -1376,36 +1011,6 @@ static inline uint32_t sched_grid(const LaunchCfg& cfg, size_t upper, bool no_me
     size_t g = need < cap ? need : cap;
     return (uint32_t)(g ? g : 1);
 }
-// Which template instance a launch needs: all mesh trees staged in LDS, none, or a mix.
-static inline int mesh_location(const DevScene& S, const LaunchCfg& cfg) {
-    if (S.n_meshes == 0) return MESH_NONE;
-    if (!cfg.use_lds || S.lds_mesh == MISS) return MESH_GLOBAL;
-    return S.n_meshes == 1 ? MESH_LDS : MESH_MIXED;
-}
-#define RTAMD_DISPATCH_LEAN(KERNEL, ML, TB, lean, grid, lds_bytes, st, ...)                                                    \
-    do {                                                                                                                    \
-        if (lean) hipLaunchKernelGGL((KERNEL<ML, TB, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);      \
-        else hipLaunchKernelGGL((KERNEL<ML, TB, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, st, __VA_ARGS__);          \
-    } while (0)
-#define RTAMD_DISPATCH_TAB(KERNEL, ML, tab, lean, grid, lds_bytes, st, ...)                                                    \
-    do {                                                                                                                    \
-        if (tab == TAB_LDS) RTAMD_DISPATCH_LEAN(KERNEL, ML, TAB_LDS, lean, grid, lds_bytes, st, __VA_ARGS__);                 \
-        else if (tab == TAB_MID) RTAMD_DISPATCH_LEAN(KERNEL, ML, TAB_MID, lean, grid, lds_bytes, st, __VA_ARGS__);            \
-        else RTAMD_DISPATCH_LEAN(KERNEL, ML, TAB_GLOBAL, lean, grid, lds_bytes, st, __VA_ARGS__);                             \
-    } while (0)
-// (lean_: the scene holds nothing beyond what the lean form of its kernel instance is compiled for, see sched_features)
-#define RTAMD_DISPATCH_MESHLOC(S, cfg, KERNEL, grid, st, ...)                                                                 \
-    do {                                                                                                                    \
-        const int loc_ = mesh_location(S, cfg);                                                                             \
-        const int tab_ = !cfg.use_lds ? TAB_GLOBAL : ((S).tab_bytes > 0 ? TAB_LDS : ((S).mid_bytes > 0 ? TAB_MID : TAB_GLOBAL));  \
-        const uint32_t lb_ = ((loc_ == MESH_LDS || loc_ == MESH_MIXED) ? (S).lds_sched_bytes : 0u) + (tab_ == TAB_LDS ? (S).tab_bytes : (tab_ == TAB_MID ? (S).mid_bytes : 0u)); \
-        const bool lean_ = cfg.lean && ((S).features & ~sched_features(loc_, true)) == 0u;                                    \
-        if (loc_ == MESH_NONE) RTAMD_DISPATCH_TAB(KERNEL, MESH_NONE, tab_, lean_, grid, lb_, st, __VA_ARGS__);                \
-        else if (loc_ == MESH_LDS) RTAMD_DISPATCH_TAB(KERNEL, MESH_LDS, tab_, lean_, grid, lb_, st, __VA_ARGS__);             \
-        else if (loc_ == MESH_MIXED) RTAMD_DISPATCH_TAB(KERNEL, MESH_MIXED, tab_, lean_, grid, lb_, st, __VA_ARGS__);         \
-        else RTAMD_DISPATCH_TAB(KERNEL, MESH_GLOBAL, tab_, lean_, grid, lb_, st, __VA_ARGS__);                                \
-    } while (0)
-
 static inline uint32_t sched_chunk(const LaunchCfg& cfg, size_t n, uint32_t grid) {
     uint32_t chunk = (uint32_t)cfg.chunk;
     const size_t waves = (size_t)grid * (TRACE_BLOCK / 64);

@@ -27,7 +27,8 @@
 
 namespace rtamd {
 
-enum : uint32_t { ST_FETCH = 0, ST_OBJ = 1, ST_TNODE = 2, ST_NODE = 3, ST_TRI = 4, ST_DONE = 5, ST_WALK = 6 /* walks its mesh by itself */ };
+enum : uint32_t { ST_FETCH = 0, ST_OBJ = 1, ST_TNODE = 2, ST_NODE = 3, ST_TRI = 4, ST_DONE = 5, ST_WALK = 6 /* walks its mesh by itself */,
+                  ST_IDLE = 7 /* per-frame kernel: wants a ray and found none ready; looks again in the next FETCH step */ };
 
 // LDS copy of mesh S.lds_mesh, addressed through LDS-typed pointers so that the loads are
 // ds_read_b128 (a generic pointer that may be LDS or global compiles to slow flat loads).
@@ -230,6 +231,7 @@ __device__ __forceinline__ void stage_row(const void* gsrc, uint32_t lds_dst) {
 //   void decode(uint32_t idx, const uint32_t (&raw)[8], f3& pos, f3& dir, float& tmax, bool& any, uint32_t& tag) const;
 //   void store_closest(uint32_t idx, uint32_t tag, bool found, const Best& b, float t_world) const;
 //   void store_any(uint32_t idx, uint32_t tag, bool occluded) const;
+//   static constexpr bool MEGA;   // false: rays come from one queue in global memory (work_head, n_items); true: see PixelPool below
 // `tag` is an opaque word the IO wants back when the result is stored (loaded with the ray, so that
 // storing never needs a dependent read).  Every address stage_addr() returns must be readable, also
 // for words the ray kind does not use.
@@ -427,6 +429,117 @@ __host__ __device__ constexpr uint32_t sched_features(int meshloc, bool lean) {
 // Mesh trees in global memory: what two 512-thread blocks per CU leave of the 160 KB; scenes without meshes run three blocks per
 // CU; beside a mesh staged in LDS three entries fit (rtamd_upload_scene keeps mesh + tables within what is left).  Scenes whose
 // tables fit LDS (at most 64 objects) have no tree worth an ordered walk.
+// ------------------------------------------------------------------------------------------------
+// Per-frame form (IO::MEGA): a wave owns up to 256 pixels for a whole launch and does everything for them.  Its lanes trace
+// the rays of those pixels; whenever all rays a pixel waits for have returned, the pixel is resumable, and the wave's
+// FETCH step runs the integrator for up to 64 resumable pixels at once (io.step: shade the hit, draw the light samples
+// and the scatter direction, start the pixel's next sample), which leaves new rays ready.  Nothing is shared between
+// waves, so there is nothing to wait for and no launch boundary between the bounces of a path or the samples of a pixel.
+//
+// State of pixel p of the wave, one LDS word (io.pix[p]):
+//   bits 0-7   rays ready to be traced (bit 0 the closest-hit ray, bit k the k-th shadow ray)
+//   bits 8-11  rays handed out or ready whose results have not come back
+//   bit  12    the pixel has samples left
+//   bits 16-31 index of the sample the pixel works on
+// A ray is named by ref = p << 3 | k.  io.pix[256 .. 319] is scratch for the lists built here.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t PW_RDY_MASK = 0xFFu, PW_PEND_ONE = 0x100u, PW_PEND_MASK = 0xF00u, PW_ALIVE = 0x1000u, PW_SAMPLE_SHIFT = 16u;
+static constexpr uint32_t POOL_PIXELS = 256u, POOL_WORDS = POOL_PIXELS + 64u;
+static constexpr uint32_t POOL_TRIP_LIMIT = 1u << 24;   // scheduler steps of a wave per launch (a 256-spp chunk of an 8K frame takes about a million)
+// IO (MEGA) concept, besides decode / store_closest / store_any:
+//   lds_u32* pix; uint32_t step_min;
+//   void ray_addr(uint32_t ref, const void* (&src)[8]) const;
+//   uint32_t step(uint32_t p, bool active) const;     // all 64 lanes call; returns the pixel's new word
+//   void finish(uint32_t lane, uint32_t n_closest, uint32_t n_any) const;
+//   void fail(uint32_t lane, uint32_t code) const;
+template <class IO, class Start>
+__device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, uint32_t& st, uint32_t& fl, uint32_t& ridx, uint32_t& rtag, const Best& best,
+                                           const float wtmax, uint32_t& rot, uint32_t& n_closest, uint32_t& n_any, Start&& start) {
+    volatile lds_u32* pix = io.pix;
+    volatile lds_u32* list = io.pix + POOL_PIXELS;
+    // (1) results of the rays that have finished
+    if (st == ST_FETCH && (fl & F_HAVE)) {
+        if (fl & F_ANY) io.store_any(ridx, rtag, (fl & F_OCC) != 0u);
+        else io.store_closest(ridx, rtag, best.obj != MISS, best, wtmax);
+        __hip_atomic_fetch_sub(io.pix + (ridx >> 3), PW_PEND_ONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const bool want = st == ST_FETCH || st == ST_IDLE;
+    fl &= want ? ~F_HAVE : ~0u;
+    const unsigned long long need = __ballot(want);
+    const uint32_t c_want = (uint32_t)__builtin_popcountll(need);
+    const uint32_t wrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+    asm volatile("" ::: "memory");
+    for (;;) {
+        // (2) every lane looks at four pixels; the scan order starts at group `rot` (round robin over the FETCH steps)
+        const uint32_t g = (lane + rot) & 63u;
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = pix[4u * g + q];
+        uint32_t own = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            own += (uint32_t)__builtin_popcount(w[q] & PW_RDY_MASK);
+            own += ((w[q] & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE) ? (1u << 13) : 0u;
+            own += (w[q] & PW_ALIVE) ? (1u << 22) : 0u;
+        }
+        const uint32_t incl = wave_scan_add(own);
+        const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t t_rdy = tot & 0x1FFFu, t_res = (tot >> 13) & 0x1FFu, t_alive = tot >> 22;
+        // (3) resumable pixels: run the integrator for them when there are enough to fill the wave, or when lanes would
+        // otherwise go without a ray
+        if (t_res > 0u && (t_res >= io.step_min || t_rdy < c_want)) {   // (every step takes its pixels off this count)
+            uint32_t pos = ((incl - own) >> 13) & 0x1FFu;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if ((w[q] & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE) {
+                    if (pos < 64u) list[pos] = 4u * g + q;
+                    pos++;
+                }
+            const uint32_t n_step = t_res < 64u ? t_res : 64u;
+            const bool act = lane < n_step;
+            const uint32_t p = act ? list[lane] : 0u;
+            const uint32_t nw = io.step(p, act);
+            if (act) pix[p] = nw;
+            asm volatile("" ::: "memory");
+            continue;
+        }
+        // (4) ready rays to the lanes that want one
+        const uint32_t take = c_want < t_rdy ? c_want : t_rdy;
+        if (take > 0u) {
+            uint32_t pos = (incl - own) & 0x1FFFu;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t bits = w[q] & PW_RDY_MASK, handed = 0u;
+                while (bits != 0u && pos < take) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(bits);
+                    list[pos++] = ((4u * g + q) << 3) | k;
+                    handed |= 1u << k;
+                    bits &= bits - 1u;
+                }
+                pos += (uint32_t)__builtin_popcount(bits);
+                if (handed) pix[4u * g + q] = w[q] & ~handed;
+            }
+            // the next step starts with the group this one ended in
+            const unsigned long long served = __ballot(((incl - own) & 0x1FFFu) < take && (own & 0x1FFFu) != 0u);
+            rot = (rot + 63u - (uint32_t)__builtin_clzll(served)) & 63u;
+        }
+        const bool got = want && wrank < take;
+        if (got) {
+            ridx = list[wrank];
+            const void* src[8];
+            io.ray_addr(ridx, src);
+            uint32_t raw[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) raw[c] = *(const uint32_t*)src[c];
+            start(raw);
+        } else if (want) st = t_alive == 0u ? ST_DONE : ST_IDLE;
+        const unsigned long long got_any = __ballot(got && (ridx & 7u) != 0u);
+        n_any += (uint32_t)__builtin_popcountll(got_any);
+        n_closest += take - (uint32_t)__builtin_popcountll(got_any);
+        break;
+    }
+}
+
 __host__ __device__ constexpr uint32_t sched_stack_depth(int meshloc, bool small_scene) {
     return meshloc == MESH_GLOBAL ? 10u : (small_scene ? 0u : (meshloc == MESH_NONE ? 7u : 3u));
 }
@@ -486,6 +599,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     uint32_t ks = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;                   // nothing is left for this wave to claim
+    uint32_t pool_rot = 0, n_closest_taken = 0, n_any_taken = 0;   // (IO::MEGA; wave-uniform)
 
     // Object trees are walked in the reference's fixed order, which is not front to back: a ray that grazes a scene of
     // thousands of objects visits every object whose box it crosses until the walk happens upon its nearest hit, and a
@@ -802,9 +916,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             }
           }
     };
+    uint32_t pool_trips = 0;
     for (;;) {
         DIAG_TOP
         TL_TRIP
+        if constexpr (IO::MEGA) {   // a wave that does not come to an end gives up (and says so) rather than hold the GPU
+            if (++pool_trips > POOL_TRIP_LIMIT) { io.fail(lane, 1u); break; }
+        }
         // ---- vote: run the phase most lanes are waiting for ----
         const uint32_t c_tri = MESHLOC != MESH_NONE ? wave_count(st == ST_TRI) : 0u;
         const uint32_t c_node = MESHLOC != MESH_NONE ? wave_count(st == ST_NODE) : 0u;
@@ -832,13 +950,15 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           // phase: inside it the rest of the lane state is loop-invariant (no copies at the loop's joins) and the vote
           // counts two states instead of five.  The sequence of phases is the one the full vote would produce.
           uint32_t ph = phase, cn = c_node;
+          // (lanes parked without a ray take no part in any vote, and none parks inside this loop)
+          const uint32_t c_off = IO::MEGA ? wave_count(st == ST_IDLE || st == ST_DONE) : 0u;
           for (;;) {
             if (ph == ST_TRI) tri_phase(); else node_phase(cn);
             const uint32_t ct2 = wave_count(st == ST_TRI);
             cn = wave_count(st == ST_NODE);
             const bool mf = Tab::small_scene || ct2 + cn >= VOTE_MESH_MIN;
             const uint32_t kt = ct2 * (mf ? VOTE_W_TRI : 1u), kn = cn * (mf ? VOTE_W_NODE : 1u);
-            const uint32_t others = (64u - ct2 - cn) * VOTE_W_OTHER_MAX;   // upper bound of any other phase's key
+            const uint32_t others = (64u - ct2 - cn - c_off) * VOTE_W_OTHER_MAX;   // upper bound of any other phase's key
             const uint32_t km = kt >= kn ? kt : kn;
             if (km == 0u || km < others) break;   // equal keys go to the deeper phase: a mesh phase
             DIAG_END(ph)
@@ -1079,7 +1199,22 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         }
         if (PLAIN_T && phase == ST_OBJ && S.plain_tree_boxes != 0u)   // (lanes enter object trees only in the OBJ phase)
             tree_exact = wave_count((fl & (F_INTREE | F_ODDW)) == (F_INTREE | F_ODDW)) != 0u;
-        if (phase == ST_FETCH) {
+        if (IO::MEGA && phase == ST_FETCH) {
+            if constexpr (IO::MEGA) {
+            DIAG_STEP(ST_FETCH, c_fetch)
+            pool_fetch(io, lane, st, fl, ridx, rtag, best, wtmax, pool_rot, n_closest_taken, n_any_taken, [&](const uint32_t (&raw)[8]) {
+                bool any;
+                io.decode(ridx, raw, wpos, wdir, wtmax, any, rtag);
+                if (S.any_box) winv = mk(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);
+                best.obj = MISS; best.prim = 0; best.t_local = 0.f; best.u = 0.f; best.v = 0.f;
+                const bool run = S.root_first != MISS;
+                root_i = run ? S.n_root : 0u; o_cur = run ? S.root_first : 0u; o_end = run ? S.root_first + S.n_root : 0u;
+                fl = any ? F_ANY : 0u;
+                st = ST_OBJ;
+            });
+            }
+        }
+        if (!IO::MEGA && phase == ST_FETCH) {
             DIAG_STEP(ST_FETCH, c_fetch)
             const bool want = st == ST_FETCH;
             // hand out staged rays to the lanes that want one
@@ -1166,6 +1301,14 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             if (st == ST_FETCH && exhausted && sg_cnt == 0) st = ST_DONE;
         }
         DIAG_END(phase)
+    }
+    if constexpr (IO::MEGA) {
+        // (every pixel must have come to its end)
+        uint32_t left = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) left |= ((volatile lds_u32*)io.pix)[4u * lane + q] & PW_ALIVE;
+        if (__ballot(left != 0u) != 0ull) io.fail(lane, 2u);
+        io.finish(lane, n_closest_taken, n_any_taken);
     }
     DIAG_FLUSH
     TL_FLUSH
