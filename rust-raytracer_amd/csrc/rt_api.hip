@@ -1111,8 +1111,10 @@ int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     WaveBufs W = ws.W;
     W.cap = (uint32_t)ws.cap;
     hipStream_t st = ws.stream;
+    rc = ensure_batch(ctx, (size_t)48 * 64 * 4 * mega_waves(ctx->S, ctx->cfg));
+    if (rc) return rc;
     const MegaFrame F{make_region(*region), make_camera(*cam), (uint32_t)integ->antialiasing, integ->max_depth, integ->shadow_rays, S_shoot,
-                      (uint32_t)ctx->frame_step_min, out};
+                      (uint32_t)ctx->frame_step_min, out, (uint32_t*)ctx->batch_buf};
     hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
     HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ev0, 0));

@@ -181,6 +181,7 @@ struct MegaFrame {
     uint32_t n_shoot;
     uint32_t step_min;   // resumable pixels of a wave from which its integrator step runs without waiting for idle lanes (1..64)
     float* out;
+    uint32_t* park;      // 48 * 64 * mega_waves() words of scratch (lane state parked around the integrator step)
 };
 uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg);
 hipError_t launch_mega(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, hipStream_t st);

@@ -35,6 +35,7 @@ struct MegaParams {
     int32_t max_depth, shadow_rays;
     uint32_t n_shoot, step_min;
     float* out;
+    uint32_t* park;   // POOL_PARK_WORDS * 64 * n_waves words
 };
 
 // slot of the chunk -> (wave, pixel of the wave): units of four consecutive slots are dealt to the waves in turn, so that
@@ -269,6 +270,8 @@ struct MegaIO {
     uint32_t base;       // state index of the wave's first pixel
     uint32_t step_min;
     uint64_t params;     // address of the kernel's argument block
+    uint32_t* park;      // lane state parked around pixel_step (rt_sched.h)
+    size_t park_stride;
     lds_u32* pix;
     __device__ __forceinline__ void stage_addr(uint32_t, const void* (&src)[8]) const {   // (the queue form's; unused)
 #pragma unroll
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
         ((volatile lds_u32*)pool)[p] = (meta & PM_VALID) ? (PW_ALIVE | 1u | PW_PEND_ONE) : 0u;
     }
     MegaIO io{P.W.q_ray[0], P.W.set[0].a_ray, P.W.set[0].a_vidx, P.W.h_rec, P.W.set[0].vis, (unsigned long long*)P.W.stats, P.W.cap, P.W.any_cap, base, P.step_min,
-              (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(), pool};
+              (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(), P.park, (size_t)P.n_waves * 64u, pool};
     if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, nullptr, 0u, 64u, pool, coop, ostack);
     else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, nullptr, 0u, 64u, pool, coop, ostack);
     else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, nullptr, 0u, 64u, pool, coop, ostack);
@@ -353,7 +356,7 @@ uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg) {
 hipError_t launch_mega(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, hipStream_t st) {
     const uint32_t n_waves = mega_waves(S, cfg);
     if (chunk_n == 0u || chunk_n > n_waves * POOL_PIXELS || F.n_shoot > 7u || F.max_depth < 1) return hipErrorInvalidValue;
-    MegaParams P{S, W, F.R, F.cam, chunk_begin, chunk_n, F.aa, n_waves, F.max_depth, F.shadow_rays, F.n_shoot, F.step_min, F.out};
+    MegaParams P{S, W, F.R, F.cam, chunk_begin, chunk_n, F.aa, n_waves, F.max_depth, F.shadow_rays, F.n_shoot, F.step_min, F.out, F.park};
     const uint32_t n_state = n_waves * POOL_PIXELS;
     const uint32_t g = n_waves / (TRACE_BLOCK / 64);
 #ifdef RTAMD_MEGA_ALL

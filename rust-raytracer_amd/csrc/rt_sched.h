@@ -445,16 +445,21 @@ __host__ __device__ constexpr uint32_t sched_features(int meshloc, bool lean) {
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t PW_RDY_MASK = 0xFFu, PW_PEND_ONE = 0x100u, PW_PEND_MASK = 0xF00u, PW_ALIVE = 0x1000u, PW_SAMPLE_SHIFT = 16u;
 static constexpr uint32_t POOL_PIXELS = 256u, POOL_WORDS = POOL_PIXELS + 64u;
+static constexpr uint32_t POOL_PARK_WORDS = 48u;   // words of lane state parked around an integrator step
+#ifndef RTAMD_MEGA_PARK
+#define RTAMD_MEGA_PARK 0
+#endif
 static constexpr uint32_t POOL_TRIP_LIMIT = 1u << 24;   // scheduler steps of a wave per launch (a 256-spp chunk of an 8K frame takes about a million)
 // IO (MEGA) concept, besides decode / store_closest / store_any:
-//   lds_u32* pix; uint32_t step_min;
+//   lds_u32* pix; uint32_t step_min; uint32_t* park; size_t park_stride;   // park: POOL_PARK_WORDS rows of park_stride words (>= lanes of the launch)
 //   void ray_addr(uint32_t ref, const void* (&src)[8]) const;
 //   uint32_t step(uint32_t p, bool active) const;     // all 64 lanes call; returns the pixel's new word
 //   void finish(uint32_t lane, uint32_t n_closest, uint32_t n_any) const;
 //   void fail(uint32_t lane, uint32_t code) const;
-template <class IO, class Start>
+template <class IO, class Start, class Before, class After>
 __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, uint32_t& st, uint32_t& fl, uint32_t& ridx, uint32_t& rtag, const Best& best,
-                                           const float wtmax, uint32_t& rot, uint32_t& n_closest, uint32_t& n_any, Start&& start) {
+                                           const float wtmax, uint32_t& rot, uint32_t& n_closest, uint32_t& n_any, Start&& start, Before&& before_step,
+                                           After&& after_step) {
     volatile lds_u32* pix = io.pix;
     volatile lds_u32* list = io.pix + POOL_PIXELS;
     // (1) results of the rays that have finished
@@ -469,75 +474,81 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
     const uint32_t c_want = (uint32_t)__builtin_popcountll(need);
     const uint32_t wrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
     asm volatile("" ::: "memory");
-    for (;;) {
-        // (2) every lane looks at four pixels; the scan order starts at group `rot` (round robin over the FETCH steps)
-        const uint32_t g = (lane + rot) & 63u;
-        uint32_t w[4];
+    // (2) every lane looks at four pixels; the scan order starts at group `rot` (round robin over the FETCH steps)
+    const uint32_t g = (lane + rot) & 63u;
+    uint32_t w[4], own, incl, t_rdy, t_res, t_alive;
+    auto scan = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; q++) w[q] = pix[4u * g + q];
-        uint32_t own = 0;
+        own = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             own += (uint32_t)__builtin_popcount(w[q] & PW_RDY_MASK);
             own += ((w[q] & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE) ? (1u << 13) : 0u;
             own += (w[q] & PW_ALIVE) ? (1u << 22) : 0u;
         }
-        const uint32_t incl = wave_scan_add(own);
+        incl = wave_scan_add(own);
         const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
-        const uint32_t t_rdy = tot & 0x1FFFu, t_res = (tot >> 13) & 0x1FFu, t_alive = tot >> 22;
-        // (3) resumable pixels: run the integrator for them when there are enough to fill the wave, or when lanes would
-        // otherwise go without a ray
-        if (t_res > 0u && (t_res >= io.step_min || t_rdy < c_want)) {   // (every step takes its pixels off this count)
-            uint32_t pos = ((incl - own) >> 13) & 0x1FFu;
+        t_rdy = tot & 0x1FFFu; t_res = (tot >> 13) & 0x1FFu; t_alive = tot >> 22;
+    };
+    scan();
+    // (3) resumable pixels: run the integrator for them when there are enough to fill the wave, or when lanes would
+    // otherwise go without a ray
+    if (t_res > 0u && (t_res >= io.step_min || t_rdy < c_want)) {
+        uint32_t pos = ((incl - own) >> 13) & 0x1FFu;
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if ((w[q] & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE) {
-                    if (pos < 64u) list[pos] = 4u * g + q;
-                    pos++;
-                }
-            const uint32_t n_step = t_res < 64u ? t_res : 64u;
-            const bool act = lane < n_step;
-            const uint32_t p = act ? list[lane] : 0u;
-            const uint32_t nw = io.step(p, act);
-            if (act) pix[p] = nw;
-            asm volatile("" ::: "memory");
-            continue;
-        }
-        // (4) ready rays to the lanes that want one
-        const uint32_t take = c_want < t_rdy ? c_want : t_rdy;
-        if (take > 0u) {
-            uint32_t pos = (incl - own) & 0x1FFFu;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t bits = w[q] & PW_RDY_MASK, handed = 0u;
-                while (bits != 0u && pos < take) {
-                    const uint32_t k = (uint32_t)__builtin_ctz(bits);
-                    list[pos++] = ((4u * g + q) << 3) | k;
-                    handed |= 1u << k;
-                    bits &= bits - 1u;
-                }
-                pos += (uint32_t)__builtin_popcount(bits);
-                if (handed) pix[4u * g + q] = w[q] & ~handed;
+        for (int q = 0; q < 4; q++)
+            if ((w[q] & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE) {
+                if (pos < 64u) list[pos] = 4u * g + q;
+                pos++;
             }
-            // the next step starts with the group this one ended in
-            const unsigned long long served = __ballot(((incl - own) & 0x1FFFu) < take && (own & 0x1FFFu) != 0u);
-            rot = (rot + 63u - (uint32_t)__builtin_clzll(served)) & 63u;
-        }
-        const bool got = want && wrank < take;
-        if (got) {
-            ridx = list[wrank];
-            const void* src[8];
-            io.ray_addr(ridx, src);
-            uint32_t raw[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) raw[c] = *(const uint32_t*)src[c];
-            start(raw);
-        } else if (want) st = t_alive == 0u ? ST_DONE : ST_IDLE;
-        const unsigned long long got_any = __ballot(got && (ridx & 7u) != 0u);
-        n_any += (uint32_t)__builtin_popcountll(got_any);
-        n_closest += take - (uint32_t)__builtin_popcountll(got_any);
-        break;
+        const uint32_t n_step = t_res < 64u ? t_res : 64u;
+        const bool act = lane < n_step;
+        const uint32_t p = act ? list[lane] : 0u;
+        before_step();
+        const uint32_t nw = io.step(p, act);
+        after_step();
+        if (act) pix[p] = nw;
+        asm volatile("" ::: "memory");
+        scan();
     }
+    // (4) ready rays to the lanes that want one
+    const uint32_t take = c_want < t_rdy ? c_want : t_rdy;
+    if (take > 0u) {
+        uint32_t pos = (incl - own) & 0x1FFFu;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t bits = w[q] & PW_RDY_MASK, handed = 0u;
+            while (bits != 0u && pos < take) {
+                const uint32_t k = (uint32_t)__builtin_ctz(bits);
+                list[pos++] = ((4u * g + q) << 3) | k;
+                handed |= 1u << k;
+                bits &= bits - 1u;
+            }
+            pos += (uint32_t)__builtin_popcount(bits);
+            if (handed) pix[4u * g + q] = w[q] & ~handed;
+        }
+        // the next step starts with the group this one ended in
+        const unsigned long long served = __ballot(((incl - own) & 0x1FFFu) < take && (own & 0x1FFFu) != 0u);
+        rot = (rot + 63u - (uint32_t)__builtin_clzll(served)) & 63u;
+    }
+    const bool got = want && wrank < take;
+    if (got) {
+        ridx = list[wrank];
+        const void* src[8];
+        io.ray_addr(ridx, src);
+        uint32_t raw[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) raw[c] = *(const uint32_t*)src[c];
+        start(raw);
+    } else if (want) {
+        // nothing for this lane: it parks until the next FETCH step (which a lane that finishes a ray brings about); while
+        // resumable pixels are left it keeps asking, so that the step for them comes even if no ray is in flight
+        st = t_alive == 0u ? ST_DONE : (t_res > 0u ? ST_FETCH : ST_IDLE);
+    }
+    const unsigned long long got_any = __ballot(got && (ridx & 7u) != 0u);
+    n_any += (uint32_t)__builtin_popcountll(got_any);
+    n_closest += take - (uint32_t)__builtin_popcountll(got_any);
 }
 
 __host__ __device__ constexpr uint32_t sched_stack_depth(int meshloc, bool small_scene) {
@@ -917,6 +928,34 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           }
     };
     uint32_t pool_trips = 0;
+    // (IO::MEGA) The integrator step is a call, and it needs the whole register file: whatever is live across it gets saved
+    // and restored by the compiler, which then makes room for that in the walks' loops as well.  The lane's state is instead
+    // written out by hand before the call and read back after it (row k of io.park: word k of every lane of the launch), so
+    // that nothing of it is live across the call.
+    constexpr bool MEGA_PARK = IO::MEGA && RTAMD_MEGA_PARK != 0;
+    auto lane_state = [&](auto save_c) {
+        if constexpr (IO::MEGA) {
+        constexpr bool SAVE = decltype(save_c)::value;
+        // (row address wave-uniform, the lane's place in it a 32-bit offset: one scalar base + one vector offset per access)
+        uint32_t* row = io.park;
+        const uint32_t at = wave_id * 64u + lane;
+        auto u = [&](uint32_t& v) {
+            if (SAVE) row[at] = v; else v = ((volatile uint32_t*)row)[at];
+            row += io.park_stride;
+        };
+        auto f = [&](float& v) {
+            if (SAVE) row[at] = __float_as_uint(v); else v = __uint_as_float(((volatile uint32_t*)row)[at]);
+            row += io.park_stride;
+        };
+        u(st); u(fl); u(ridx); u(rtag);
+        f(wpos.x); f(wpos.y); f(wpos.z); f(wdir.x); f(wdir.y); f(wdir.z); f(winv.x); f(winv.y); f(winv.z); f(wtmax);
+        u(best.obj); u(best.prim); f(best.t_local); f(best.u); f(best.v);
+        u(root_i); u(t_i); u(t_n); u(t_base); u(t_first); f(t_lim); u(o_cur); u(o_end); u(oi);
+        f(opos.x); f(opos.y); f(opos.z); f(odir.x); f(odir.y); f(odir.z); f(oinv.x); f(oinv.y); f(oinv.z); f(otmax); f(oscale);
+        u(n_i); u(n_n); u(node_off); u(tri_off); u(k_cur); u(k_end); u(oprim); f(ou); f(ov);
+        }
+    };
+    static_assert(POOL_PARK_WORDS >= 48u, "rows of the parking area");
     for (;;) {
         DIAG_TOP
         TL_TRIP
@@ -1199,7 +1238,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         }
         if (PLAIN_T && phase == ST_OBJ && S.plain_tree_boxes != 0u)   // (lanes enter object trees only in the OBJ phase)
             tree_exact = wave_count((fl & (F_INTREE | F_ODDW)) == (F_INTREE | F_ODDW)) != 0u;
-        if (IO::MEGA && phase == ST_FETCH) {
+        if (IO::MEGA && __builtin_expect(phase == ST_FETCH, 0)) {
             if constexpr (IO::MEGA) {
             DIAG_STEP(ST_FETCH, c_fetch)
             pool_fetch(io, lane, st, fl, ridx, rtag, best, wtmax, pool_rot, n_closest_taken, n_any_taken, [&](const uint32_t (&raw)[8]) {
@@ -1211,7 +1250,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 root_i = run ? S.n_root : 0u; o_cur = run ? S.root_first : 0u; o_end = run ? S.root_first + S.n_root : 0u;
                 fl = any ? F_ANY : 0u;
                 st = ST_OBJ;
-            });
+            }, [&]() { if (MEGA_PARK) lane_state(std::true_type{}); }, [&]() { if (MEGA_PARK) lane_state(std::false_type{}); });
             }
         }
         if (!IO::MEGA && phase == ST_FETCH) {
