@@ -340,13 +340,17 @@ enum rtamd_option {
                                      trees 8 beside them, 14 in scenes without meshes, 6 beside a mesh staged in LDS) of the per-lane stack
                                      an ordered walk may use; where it is full, the subtree at hand is walked in the reference's order.
                                      Same hits at any value (a test knob) */
-    RTAMD_OPT_FRAME_KERNEL = 15,  /* rtamd_render* with scatter_rays = 1: 1 the whole integrator as one launch per 256 * waves pixels (every
-                                     wave owns its pixels from the first camera ray to the last sample: no chain of launches); 0 the
+    RTAMD_OPT_FRAME_KERNEL = 15,  /* rtamd_render* with scatter_rays = 1: 1 the whole integrator in a few launches per 256 * waves pixels (every
+                                     wave owns a range of pixels and runs them from the first camera ray on: no chain of launches); 0 the
                                      wavefront pipeline (a trace, a resolve and a shade launch per sample and bounce).  Same pixels, bit for
                                      bit, same ray counts.  Scenes with more than 7 shadow rays per lit hit, max_depth = 0 and kernel
                                      instances the mode is not built for take the pipeline */
     RTAMD_OPT_FRAME_STEP_MIN = 16, /* frame kernel: resumable pixels (1..64, default 64) from which a wave runs its integrator step
                                      without waiting for lanes to go idle */
+    RTAMD_OPT_FRAME_REBALANCE = 17, /* frame kernel, 8 samples per pixel or more: how often (0..6, default 3) the pixel ranges of the waves are
+                                     cut anew for equal cost, from the rays and the time the launch before measured: the samples are
+                                     rendered in value + 1 launches, [0, 1) [1, 4) [4, 16) ... ; 0 one launch, ranges of equal length.
+                                     Same pixels at any value */
     RTAMD_OPT_STRICT_ORDER = 13   /* 1: RTAMD_OPT_TREE_DEEPENING = 0 and RTAMD_OPT_ORDERED_WALK = 0 in one call: every entry point visits
                                      nodes, objects and triangles in the reference's order, with no excepted ray; 0: both back to their
                                      defaults */

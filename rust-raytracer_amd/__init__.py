@@ -32,6 +32,7 @@ OPT_STRICT_ORDER = 13
 OPT_ORDERED_STACK = 14
 OPT_FRAME_KERNEL = 15
 OPT_FRAME_STEP_MIN = 16
+OPT_FRAME_REBALANCE = 17
 
 _f32p = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)

@@ -32,6 +32,7 @@ struct rtamd_context {
     uint32_t ordered_cap = 15; // stack entries an ordered walk may use (RTAMD_OPT_ORDERED_STACK)
     int frame_kernel = 0;    // RTAMD_OPT_FRAME_KERNEL
     int frame_step_min = 64; // RTAMD_OPT_FRAME_STEP_MIN
+    int frame_rebalance = 3; // RTAMD_OPT_FRAME_REBALANCE
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
@@ -426,6 +427,10 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
         case RTAMD_OPT_FRAME_STEP_MIN:
             if (value < 1 || value > 64) return fail(ctx, RTAMD_E_INVALID, "frame step threshold must be in [1, 64]");
             ctx->frame_step_min = (int)value;
+            return RTAMD_OK;
+        case RTAMD_OPT_FRAME_REBALANCE:
+            if (value < 0 || value > 6) return fail(ctx, RTAMD_E_INVALID, "frame rebalance count must be in [0, 6]");
+            ctx->frame_rebalance = (int)value;
             return RTAMD_OK;
         case RTAMD_OPT_STRICT_ORDER:
             ctx->deepen = value != 0 ? 0 : 1; ctx->S.deepen = ctx->deepen >= 1 ? 1u : 0u;
@@ -1099,11 +1104,14 @@ int render_depth_first_rounds(rtamd_context* ctx, const rtamd_camera* cam, const
     return RTAMD_OK;
 }
 
-// scatter_rays = 1 as one launch per chunk of 256 * waves pixel slots (rt_mega.hip).  RTAMD_E_UNSUPPORTED: the kernel instance the
-// scene needs is not built in this mode (the caller takes the pipeline).
+// scatter_rays = 1 with every wave owning a range of pixels from their first camera ray on (rt_mega.hip): per chunk of
+// 256 * waves pixel slots one seeding launch, then one launch per window of the pixels' samples: [0, 1) over ranges of equal
+// length, then [1, 4), [4, 16), [16, ...) (as many as RTAMD_OPT_FRAME_REBALANCE says), each with the units of 64 pixel slots dealt
+// to the waves for equal cost by what the window before it measured.
 int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, size_t total_slots,
                         uint32_t S_total, uint32_t S_shoot, float* out, rtamd_stats* stats) {
-    const size_t cap = (size_t)mega_waves(ctx->S, ctx->cfg) * 256u;
+    const uint32_t n_waves = mega_waves(ctx->S, ctx->cfg);
+    const size_t cap = (size_t)n_waves * 256u;
     if (ctx->ws.empty()) ctx->ws.resize(1);
     rtamd_context::Workspace& ws = ctx->ws[0];
     int rc = ensure_wave(ctx, ws, cap, S_total);
@@ -1111,29 +1119,73 @@ int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     WaveBufs W = ws.W;
     W.cap = (uint32_t)ws.cap;
     hipStream_t st = ws.stream;
-    rc = ensure_batch(ctx, (size_t)48 * 64 * 4 * mega_waves(ctx->S, ctx->cfg));
+    const size_t park_words = (size_t)48 * 64 * n_waves, range_words = (size_t)n_waves * 7, group_words = cap / 64 + 1;
+    const bool tree = integ->scatter_rays != 1;
+    const size_t stack_words = tree ? (size_t)integ->max_depth * 20 * ws.cap : 0;
+    rc = ensure_batch(ctx, (park_words + range_words + 2 * group_words + 2 * (size_t)n_waves + stack_words) * 4);
     if (rc) return rc;
+    uint32_t* park = (uint32_t*)ctx->batch_buf;
     const MegaFrame F{make_region(*region), make_camera(*cam), (uint32_t)integ->antialiasing, integ->max_depth, integ->shadow_rays, S_shoot,
-                      (uint32_t)ctx->frame_step_min, out, (uint32_t*)ctx->batch_buf};
+                      (uint32_t)ctx->frame_step_min, out, park, park + park_words, park + park_words + range_words, park + park_words + range_words + group_words,
+                      integ->scatter_rays, (float*)(park + park_words + range_words + 2 * group_words + 2 * (size_t)n_waves),
+                      park + park_words + range_words + 2 * group_words};
+    const uint32_t n_samples = (uint32_t)integ->antialiasing * (uint32_t)integ->antialiasing;
+    // windows of samples: [0, 1) [1, w1) [w1, n); few samples, or rebalancing off: one window
+    std::vector<uint32_t> ends;
+    if (n_samples >= (tree ? 4u : 8u))
+        for (uint32_t k = 0, e = 1; k < (uint32_t)ctx->frame_rebalance && e * 2u <= n_samples; k++, e *= 4u) ends.push_back(e);
+    ends.push_back(n_samples);
     hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
     HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ev0, 0));
     HIP_TRY(ctx, hipMemsetAsync(W.stats, 0, 32, st));
     uint64_t launches = 0;
+    std::vector<uint32_t> units(range_words), owner(group_words);
+    std::vector<float> costs(group_words);
     for (size_t begin = 0; begin < total_slots; begin += cap) {
         const uint32_t chunk_n = (uint32_t)std::min(cap, total_slots - begin);
-        timed_begin(ctx, 0, st);
-        const hipError_t e = launch_mega(ctx->S, ctx->cfg, W, F, (uint32_t)begin, chunk_n, st);
-        timed_end(ctx, st);
-        if (e == hipErrorNotSupported && begin == 0) {
-            (void)hipStreamSynchronize(st);
-            ctx->event_pool.push_back(ev0);
-            ctx->event_pool.push_back(ev1);
-            ctx->timed.clear();
-            return RTAMD_E_UNSUPPORTED;
+        HIP_TRY(ctx, launch_mega_init(ctx->S, ctx->cfg, W, F, (uint32_t)begin, chunk_n, st));
+        launches++;
+        uint32_t s_begin = 0;
+        for (size_t k = 0; k < ends.size(); k++) {
+            if (k > 0) {   // ranges of equal cost by the rays counted so far
+                HIP_TRY(ctx, launch_mega_group_cost(ctx->S, ctx->cfg, W, F, chunk_n, st));
+                launches++;
+                HIP_TRY(ctx, hipMemcpyAsync(costs.data(), F.group_cost, ((size_t)chunk_n + 63) / 64 * 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+            }
+            mega_assign(k > 0 ? costs.data() : nullptr, chunk_n, n_waves, units.data(), owner.data());
+            HIP_TRY(ctx, hipMemcpyAsync(F.units, units.data(), range_words * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(F.owner, owner.data(), ((size_t)chunk_n + 63) / 64 * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));   // (the table is reused for the next window)
+            timed_begin(ctx, 0, st);
+            HIP_TRY(ctx, launch_mega(ctx->S, ctx->cfg, W, F, (uint32_t)begin, chunk_n, s_begin, ends[k], st));
+            timed_end(ctx, st);
+            launches++;
+            if (std::getenv("RTAMD_FRAME_DEBUG")) {   // how even the window's waves were
+                std::vector<uint32_t> ticks(n_waves);
+                HIP_TRY(ctx, hipMemcpyAsync(ticks.data(), F.wave_scale + n_waves, (size_t)n_waves * 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                double sum = 0; uint32_t mx = 0, used = 0, most = 0, argmax = 0;
+                auto held = [&](uint32_t w) { uint32_t n = 0; for (uint32_t q = 0; q < 7; q++) n += units[(size_t)w * 7 + q] != 0xFFFFFFFFu; return n; };
+                for (uint32_t w = 0; w < n_waves; w++) {
+                    const uint32_t n = held(w);
+                    if (!n) continue;
+                    used++; sum += ticks[w];
+                    if (ticks[w] > mx) { mx = ticks[w]; argmax = w; }
+                    most = std::max(most, n);
+                }
+                {   // by the wave's place in its block (wave numbering runs over the blocks first)
+                    const uint32_t per = n_waves / 8;
+                    std::fprintf(stderr, "  mean ticks by wave of the block:");
+                    for (uint32_t k = 0; k < 8; k++) { double t = 0; for (uint32_t b = 0; b < per; b++) t += ticks[k * per + b]; std::fprintf(stderr, " %.0f", t / per); }
+                    std::fprintf(stderr, "\n");
+                }
+                std::fprintf(stderr, "frame kernel: samples [%u, %u): %u waves with pixels, ticks mean %.0f max %u (x%.2f; wave %u with %u units), most units %u\n",
+                             s_begin, ends[k], used, sum / std::max(1u, used), mx, mx / (sum / std::max(1u, used)), argmax, held(argmax), most);
+            }
+            s_begin = ends[k];
         }
-        HIP_TRY(ctx, e);
-        launches += 2;
     }
     uint64_t hstats[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(hstats, W.stats, 32, hipMemcpyDeviceToHost, st));
@@ -1154,8 +1206,9 @@ int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
         stats->device_ms = ms;
     }
     timed_collect(ctx, stats);
-    // (1: a wave gave up after its step limit, 2: a wave ended with pixels unfinished, 3 / 4: a pixel or hit record out of range)
-    if (hstats[2] != 0) return fail(ctx, RTAMD_E_DEVICE, ("frame kernel: internal error " + std::to_string(hstats[2])).c_str());
+    // (1: a wave gave up after its step limit, 2: a wave ended with pixels unfinished, 3 / 4: a pixel or hit record out of range, 5: a
+    // range longer than a wave's pool)
+    if (hstats[2] != 0) return fail(ctx, RTAMD_E_DEVICE, "frame kernel: internal error " + std::to_string(hstats[2]));
     return RTAMD_OK;
 }
 }  // namespace
@@ -1190,13 +1243,13 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     if (integ->scatter_rays != 1) {
         // the round pipeline needs a ray per pixel to start with (max_depth >= 1); RTAMD_OPT_DEPTH_FIRST_ROUNDS = 0 selects
         // the one-lane-per-pixel kernel
+        if (ctx->frame_kernel && integ->max_depth >= 1 && integ->max_depth <= 255 && S_shoot <= 7 && mega_supported(ctx->S, ctx->cfg))
+            return render_frame_kernel(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
         if (ctx->df_rounds && integ->max_depth >= 1) return render_depth_first_rounds(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
         return render_depth_first(ctx, cam, integ, region, total_slots, out, stats);
     }
-    if (ctx->frame_kernel && integ->max_depth >= 1 && S_shoot <= 7) {
-        const int rc = render_frame_kernel(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
-        if (rc != RTAMD_E_UNSUPPORTED) return rc;
-    }
+    if (ctx->frame_kernel && integ->max_depth >= 1 && S_shoot <= 7 && mega_supported(ctx->S, ctx->cfg))
+        return render_frame_kernel(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
     // pixel groups: at most n_streams in flight, none smaller than 64 Ki pixels unless the region is
     const size_t G = (size_t)ctx->n_streams;
     size_t cap = (total_slots + G - 1) / G;
@@ -1490,6 +1543,13 @@ int rtamd_diag_read(rtamd_context* ctx, unsigned long long out[32], int reset) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, rtamd::diag_read(out, reset));
+    return RTAMD_OK;
+}
+int rtamd_diag_read_frame(rtamd_context* ctx, unsigned long long out[48], int reset) {
+    if (!ctx) return RTAMD_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, rtamd::mega_diag_read(out, reset));
     return RTAMD_OK;
 }
 // Ticks (10 ns) along the shade kernel's dependency chain as seen by its first thread: out[k] summed over launches,

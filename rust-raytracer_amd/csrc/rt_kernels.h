@@ -170,9 +170,11 @@ struct DfFrame {
 hipError_t launch_df_begin(const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t out_base, hipStream_t st);
 hipError_t launch_df_step(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const DfFrame& F, uint32_t chunk_begin, uint32_t cur, uint32_t in_base,
                           uint32_t out_base, uint32_t zero_base, size_t upper, hipStream_t st);
-// The integrator of scatter_rays = 1 as one launch per chunk (rt_mega.hip): every wave owns up to 256 pixels from their first camera ray
-// to their last sample.  A launch takes at most 256 * mega_waves() pixel slots; n_shoot (shadow rays per lit hit) at most 7,
-// max_depth at least 1.  Uses the per-slot arrays of W (capacity at least 256 * mega_waves()).
+// The integrator of scatter_rays = 1 with every wave owning a range of pixel slots from their first camera ray on (rt_mega.hip).
+// A chunk holds at most 256 * mega_waves() slots (and W.cap); n_shoot (shadow rays per lit hit) at most 7, max_depth at least 1.
+// launch_mega_init once per chunk, then launch_mega for consecutive windows [s_begin, s_end) of the pixels' samples up to
+// antialiasing^2, each with the waves' units (mega_assign) in F.units / F.owner; launch_mega_group_cost leaves in F.group_cost
+// what the next window's units are dealt by.
 struct MegaFrame {
     RegionDev R;
     CameraDev cam;
@@ -182,9 +184,21 @@ struct MegaFrame {
     uint32_t step_min;   // resumable pixels of a wave from which its integrator step runs without waiting for idle lanes (1..64)
     float* out;
     uint32_t* park;      // 48 * 64 * mega_waves() words of scratch (lane state parked around the integrator step)
+    uint32_t* units;     // 7 words per wave (device): mega_assign
+    uint32_t* owner;     // one word per unit of 64 slots (device): mega_assign
+    uint32_t* group_cost;   // one word (a float) per unit (device)
+    int32_t scatter_rays;   // != 1: one launch_mega over all samples; needs `stack`
+    float* stack;           // scatter_rays != 1: max_depth * 20 * W.cap floats (device)
+    uint32_t* wave_scale;   // 2 * mega_waves() words (device)
 };
 uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg);
-hipError_t launch_mega(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, hipStream_t st);
+bool mega_supported(const DevScene& S, const LaunchCfg& cfg);
+hipError_t launch_mega_init(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, hipStream_t st);
+hipError_t launch_mega(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t s_begin,
+                       uint32_t s_end, hipStream_t st);
+hipError_t launch_mega_group_cost(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_n, hipStream_t st);
+// cost: host copy of F.group_cost (null: the first deal); units: 7 * mega_waves() words, owner: one per unit (host)
+void mega_assign(const float* cost, uint32_t chunk_n, uint32_t n_waves, uint32_t* units, uint32_t* owner);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 // The reference's binned-SAH tree over n boxes (6 floats each, device memory), built on the GPU (rt_bvh.hip).
 // nodes_out: room for 2 n records; *n_nodes_out includes the sentinel; order_out: n primitive indices in tree order.
@@ -197,6 +211,7 @@ hipError_t timeline_dump(unsigned long long* out, size_t words, int reset);
 #ifdef RTAMD_DIAG
 hipError_t diag_read(unsigned long long* out, int reset);
 hipError_t diag_read_shade(unsigned long long* out, int reset);
+hipError_t mega_diag_read(unsigned long long* out48, int reset);   // the frame kernel's counters (rt_sched.h: g_diag)
 #endif
 
 }  // namespace rtamd

@@ -131,17 +131,20 @@ static constexpr uint32_t VOTE_W_TRI = VOTE_W[0], VOTE_W_NODE = VOTE_W[1], VOTE_
 // Diagnostic build only (-DRTAMD_DIAG): per-phase cycle, step and active-lane totals of the scheduler,
 // accumulated per wave and added to a global table when the wave ends.  Never compiled into librtamd.so.
 #ifdef RTAMD_DIAG
-__device__ unsigned long long g_diag[32];
-#define DIAG_DECL unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_steps[6] = {0, 0, 0, 0, 0, 0}, d_lanes[6] = {0, 0, 0, 0, 0, 0}; unsigned long long d_t0 = 0; unsigned long long d_sub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d_subn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// (one copy per kernel file: each file's read-out function reads its own)
+// [32..]: frame kernel: waves, sum / max of wave lifetimes, integrator steps, pixels stepped, ticks inside the step, FETCH steps, rays handed
+// out, lanes that asked, lanes left without a ray, ticks waiting for the rays' words
+static __device__ unsigned long long g_diag[48];
+#define DIAG_DECL unsigned long long d_pool[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long d_born = __builtin_amdgcn_s_memtime(); unsigned long long d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_steps[6] = {0, 0, 0, 0, 0, 0}, d_lanes[6] = {0, 0, 0, 0, 0, 0}; unsigned long long d_t0 = 0; unsigned long long d_sub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d_subn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define DIAG_TOP d_t0 = __builtin_amdgcn_s_memtime();
 #define DIAG_STEP(ph, c) { d_steps[ph] += 1; d_lanes[ph] += (c); }
 #define DIAG_END(ph) { d_cyc[ph] += __builtin_amdgcn_s_memtime() - d_t0; }
 #define DIAG_SUB_BEGIN unsigned long long d_s0 = __builtin_amdgcn_s_memtime();
 #define DIAG_SUB_END(slot) { d_sub[slot] += __builtin_amdgcn_s_memtime() - d_s0; d_subn[slot] += 1; }
 #define DIAG_SUB_MARK d_s0 = __builtin_amdgcn_s_memtime();
-#define DIAG_FLUSH if (lane == 0) { for (int q = 0; q < 8; q++) { atomicAdd(&g_diag[15 + 2 * q], d_sub[q]); atomicAdd(&g_diag[16 + 2 * q], d_subn[q]); } } if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
+#define DIAG_FLUSH if (IO::MEGA && lane == 0) { const unsigned long long life = __builtin_amdgcn_s_memtime() - d_born; atomicAdd(&g_diag[32], 1ull); atomicAdd(&g_diag[33], life); atomicMax(&g_diag[34], life); for (int q = 0; q < 8; q++) atomicAdd(&g_diag[35 + q], d_pool[q]); } if (lane == 0) { for (int q = 0; q < 8; q++) { atomicAdd(&g_diag[15 + 2 * q], d_sub[q]); atomicAdd(&g_diag[16 + 2 * q], d_subn[q]); } } if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
 #else
-#define DIAG_DECL
+#define DIAG_DECL unsigned long long* const d_pool = nullptr;
 #define DIAG_TOP
 #define DIAG_STEP(ph, c)
 #define DIAG_END(ph)
@@ -430,21 +433,27 @@ __host__ __device__ constexpr uint32_t sched_features(int meshloc, bool lean) {
 // CU; beside a mesh staged in LDS three entries fit (rtamd_upload_scene keeps mesh + tables within what is left).  Scenes whose
 // tables fit LDS (at most 64 objects) have no tree worth an ordered walk.
 // ------------------------------------------------------------------------------------------------
-// Per-frame form (IO::MEGA): a wave owns up to 256 pixels for a whole launch and does everything for them.  Its lanes trace
+// Per-frame form (IO::MEGA): a wave owns up to 448 pixels for a whole launch and does everything for them.  Its lanes trace
 // the rays of those pixels; whenever all rays a pixel waits for have returned, the pixel is resumable, and the wave's
 // FETCH step runs the integrator for up to 64 resumable pixels at once (io.step: shade the hit, draw the light samples
 // and the scatter direction, start the pixel's next sample), which leaves new rays ready.  Nothing is shared between
 // waves, so there is nothing to wait for and no launch boundary between the bounces of a path or the samples of a pixel.
 //
 // State of pixel p of the wave, one LDS word (io.pix[p]):
+// (every lane looks after 7 of them in the scans below: 64 x 7 words + 64 words of list = the 2 KB of the ray staging buffer)
 //   bits 0-7   rays ready to be traced (bit 0 the closest-hit ray, bit k the k-th shadow ray)
 //   bits 8-11  rays handed out or ready whose results have not come back
 //   bit  12    the pixel has samples left
 //   bits 16-31 index of the sample the pixel works on
-// A ray is named by ref = p << 3 | k.  io.pix[256 .. 319] is scratch for the lists built here.
+// A ray is named by ref = p << 3 | k.  io.pix[448 .. 511] is scratch for the lists built here.
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t PW_RDY_MASK = 0xFFu, PW_PEND_ONE = 0x100u, PW_PEND_MASK = 0xF00u, PW_ALIVE = 0x1000u, PW_SAMPLE_SHIFT = 16u;
-static constexpr uint32_t POOL_PIXELS = 256u, POOL_WORDS = POOL_PIXELS + 64u;
+static constexpr uint32_t POOL_PER_LANE = 7u;   // pixels a lane looks after in the FETCH step's scans
+static constexpr uint32_t POOL_PIXELS = 64u * POOL_PER_LANE, POOL_WORDS = POOL_PIXELS + 64u;
+#ifndef RTAMD_POOL_AHEAD
+#define RTAMD_POOL_AHEAD 0
+#endif
+static constexpr uint32_t POOL_AHEAD = RTAMD_POOL_AHEAD;   // pixels up to this many samples ahead of the wave's last one are served with it
 static constexpr uint32_t POOL_PARK_WORDS = 48u;   // words of lane state parked around an integrator step
 #ifndef RTAMD_MEGA_PARK
 #define RTAMD_MEGA_PARK 0
@@ -456,57 +465,86 @@ static constexpr uint32_t POOL_TRIP_LIMIT = 1u << 24;   // scheduler steps of a 
 //   uint32_t step(uint32_t p, bool active) const;     // all 64 lanes call; returns the pixel's new word
 //   void finish(uint32_t lane, uint32_t n_closest, uint32_t n_any) const;
 //   void fail(uint32_t lane, uint32_t code) const;
+#ifdef RTAMD_DIAG
+#define POOL_DIAG(...) __VA_ARGS__
+#else
+#define POOL_DIAG(...)
+#endif
 template <class IO, class Start, class Before, class After>
 __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, uint32_t& st, uint32_t& fl, uint32_t& ridx, uint32_t& rtag, const Best& best,
                                            const float wtmax, uint32_t& rot, uint32_t& n_closest, uint32_t& n_any, Start&& start, Before&& before_step,
-                                           After&& after_step) {
+                                           After&& after_step, unsigned long long* dp /* diagnostic build: counters */) {
     volatile lds_u32* pix = io.pix;
     volatile lds_u32* list = io.pix + POOL_PIXELS;
-    // (1) results of the rays that have finished
-    if (st == ST_FETCH && (fl & F_HAVE)) {
-        if (fl & F_ANY) io.store_any(ridx, rtag, (fl & F_OCC) != 0u);
-        else io.store_closest(ridx, rtag, best.obj != MISS, best, wtmax);
-        __hip_atomic_fetch_sub(io.pix + (ridx >> 3), PW_PEND_ONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    // (1) the rays that have finished count as returned from here on; their results are written further down, behind the loads of
+    // the new rays (a wait for those loads would otherwise wait for the stores before them as well)
+    const bool had = st == ST_FETCH && (fl & F_HAVE) != 0u;
+    if (had) __hip_atomic_fetch_sub(io.pix + (ridx >> 3), PW_PEND_ONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const bool want = st == ST_FETCH || st == ST_IDLE;
     fl &= want ? ~F_HAVE : ~0u;
     const unsigned long long need = __ballot(want);
     const uint32_t c_want = (uint32_t)__builtin_popcountll(need);
     const uint32_t wrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+    const uint32_t old_ridx = ridx, old_rtag = rtag;
+    bool written = false;   // (wave-uniform)
+    auto write_results = [&]() {
+        if (!written && had) {
+            if (fl & F_ANY) io.store_any(old_ridx, old_rtag, (fl & F_OCC) != 0u);
+            else io.store_closest(old_ridx, old_rtag, best.obj != MISS, best, wtmax);
+        }
+        written = true;
+    };
     asm volatile("" ::: "memory");
-    // (2) every lane looks at four pixels; the scan order starts at group `rot` (round robin over the FETCH steps)
+    // (2) every lane looks at its pixels; the scan order starts at group `rot` (round robin over the FETCH steps).  Pixels on the
+    // lowest sample index of the wave (class A) come first in both lists below: a pixel whose paths are long needs several times
+    // the steps per sample of one that looks at the sky, and served in turn it would still be on its first samples when the
+    // others are done, alone in the wave, one ray at a time.  Served first, the wave's pixels advance through their samples together.
     const uint32_t g = (lane + rot) & 63u;
-    uint32_t w[4], own, incl, t_rdy, t_res, t_alive;
+    constexpr int PPL = (int)POOL_PER_LANE;
+    uint32_t w[PPL], own, ownA, incl, inclA, t_rdy, t_res, t_alive, tA_rdy, tA_res, smin;
+    auto is_res = [](uint32_t x) { return (x & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE; };
     auto scan = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; q++) w[q] = pix[4u * g + q];
-        own = 0;
+        for (int q = 0; q < PPL; q++) w[q] = pix[POOL_PER_LANE * g + q];
+        uint32_t inv = 0u;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            own += (uint32_t)__builtin_popcount(w[q] & PW_RDY_MASK);
-            own += ((w[q] & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE) ? (1u << 13) : 0u;
-            own += (w[q] & PW_ALIVE) ? (1u << 22) : 0u;
+        for (int q = 0; q < PPL; q++) inv = max(inv, (w[q] & PW_ALIVE) ? 0x10000u - (w[q] >> PW_SAMPLE_SHIFT) : 0u);
+        smin = 0x10000u - __builtin_amdgcn_readlane(wave_scan_max(inv), 63);
+        own = 0; ownA = 0;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+            const bool a = (w[q] & PW_ALIVE) && (w[q] >> PW_SAMPLE_SHIFT) <= smin + POOL_AHEAD;
+            const uint32_t r = (uint32_t)__builtin_popcount(w[q] & PW_RDY_MASK), e = is_res(w[q]) ? (1u << 13) : 0u;
+            own += r + e + ((w[q] & PW_ALIVE) ? (1u << 22) : 0u);
+            ownA += a ? r + e : 0u;
         }
         incl = wave_scan_add(own);
-        const uint32_t tot = __builtin_amdgcn_readlane(incl, 63);
+        inclA = wave_scan_add(ownA);
+        const uint32_t tot = __builtin_amdgcn_readlane(incl, 63), totA = __builtin_amdgcn_readlane(inclA, 63);
         t_rdy = tot & 0x1FFFu; t_res = (tot >> 13) & 0x1FFu; t_alive = tot >> 22;
+        tA_rdy = totA & 0x1FFFu; tA_res = (totA >> 13) & 0x1FFu;
     };
     scan();
     // (3) resumable pixels: run the integrator for them when there are enough to fill the wave, or when lanes would
     // otherwise go without a ray
     if (t_res > 0u && (t_res >= io.step_min || t_rdy < c_want)) {
-        uint32_t pos = ((incl - own) >> 13) & 0x1FFu;
+        uint32_t posA = ((inclA - ownA) >> 13) & 0x1FFu;
+        uint32_t posB = tA_res + (((incl - own) >> 13) & 0x1FFu) - posA;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if ((w[q] & (PW_ALIVE | PW_PEND_MASK | PW_RDY_MASK)) == PW_ALIVE) {
-                if (pos < 64u) list[pos] = 4u * g + q;
-                pos++;
+        for (int q = 0; q < PPL; q++)
+            if (is_res(w[q])) {
+                const bool a = (w[q] >> PW_SAMPLE_SHIFT) <= smin + POOL_AHEAD;
+                const uint32_t pos = a ? posA++ : posB++;
+                if (pos < 64u) list[pos] = POOL_PER_LANE * g + q;
             }
         const uint32_t n_step = t_res < 64u ? t_res : 64u;
         const bool act = lane < n_step;
         const uint32_t p = act ? list[lane] : 0u;
+        write_results();   // (the step reads them)
         before_step();
+        POOL_DIAG(const unsigned long long ps0 = __builtin_amdgcn_s_memtime();)
         const uint32_t nw = io.step(p, act);
+        POOL_DIAG(dp[0] += 1; dp[1] += n_step; dp[2] += __builtin_amdgcn_s_memtime() - ps0;)
         after_step();
         if (act) pix[p] = nw;
         asm volatile("" ::: "memory");
@@ -515,37 +553,45 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
     // (4) ready rays to the lanes that want one
     const uint32_t take = c_want < t_rdy ? c_want : t_rdy;
     if (take > 0u) {
-        uint32_t pos = (incl - own) & 0x1FFFu;
+        uint32_t posA = (inclA - ownA) & 0x1FFFu;
+        uint32_t posB = tA_rdy + ((incl - own) & 0x1FFFu) - posA;
+        bool any_handed = false;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < PPL; q++) {
             uint32_t bits = w[q] & PW_RDY_MASK, handed = 0u;
+            const bool a = (w[q] >> PW_SAMPLE_SHIFT) <= smin + POOL_AHEAD;
+            uint32_t pos = a ? posA : posB;
             while (bits != 0u && pos < take) {
                 const uint32_t k = (uint32_t)__builtin_ctz(bits);
-                list[pos++] = ((4u * g + q) << 3) | k;
+                list[pos++] = ((POOL_PER_LANE * g + q) << 3) | k;
                 handed |= 1u << k;
                 bits &= bits - 1u;
             }
             pos += (uint32_t)__builtin_popcount(bits);
-            if (handed) pix[4u * g + q] = w[q] & ~handed;
+            if (a) posA = pos; else posB = pos;
+            if (handed) { pix[POOL_PER_LANE * g + q] = w[q] & ~handed; any_handed = true; }
         }
         // the next step starts with the group this one ended in
-        const unsigned long long served = __ballot(((incl - own) & 0x1FFFu) < take && (own & 0x1FFFu) != 0u);
+        const unsigned long long served = __ballot(any_handed);
         rot = (rot + 63u - (uint32_t)__builtin_clzll(served)) & 63u;
     }
     const bool got = want && wrank < take;
+    uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (got) {
         ridx = list[wrank];
         const void* src[8];
         io.ray_addr(ridx, src);
-        uint32_t raw[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) raw[c] = *(const uint32_t*)src[c];
-        start(raw);
-    } else if (want) {
+    }
+    write_results();
+    if (got) start(raw);
+    else if (want) {
         // nothing for this lane: it parks until the next FETCH step (which a lane that finishes a ray brings about); while
         // resumable pixels are left it keeps asking, so that the step for them comes even if no ray is in flight
         st = t_alive == 0u ? ST_DONE : (t_res > 0u ? ST_FETCH : ST_IDLE);
     }
+    POOL_DIAG(dp[3] += 1; dp[4] += take; dp[5] += c_want; dp[6] += c_want - take;)
     const unsigned long long got_any = __ballot(got && (ridx & 7u) != 0u);
     n_any += (uint32_t)__builtin_popcountll(got_any);
     n_closest += take - (uint32_t)__builtin_popcountll(got_any);
@@ -1250,7 +1296,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 root_i = run ? S.n_root : 0u; o_cur = run ? S.root_first : 0u; o_end = run ? S.root_first + S.n_root : 0u;
                 fl = any ? F_ANY : 0u;
                 st = ST_OBJ;
-            }, [&]() { if (MEGA_PARK) lane_state(std::true_type{}); }, [&]() { if (MEGA_PARK) lane_state(std::false_type{}); });
+            }, [&]() { if (MEGA_PARK) lane_state(std::true_type{}); }, [&]() { if (MEGA_PARK) lane_state(std::false_type{}); }, d_pool);
             }
         }
         if (!IO::MEGA && phase == ST_FETCH) {
@@ -1345,7 +1391,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         // (every pixel must have come to its end)
         uint32_t left = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < 4u; q++) left |= ((volatile lds_u32*)io.pix)[4u * lane + q] & PW_ALIVE;
+        for (uint32_t q = 0; q < POOL_PER_LANE; q++) left |= ((volatile lds_u32*)io.pix)[POOL_PER_LANE * lane + q] & PW_ALIVE;
         if (__ballot(left != 0u) != 0ull) io.fail(lane, 2u);
         io.finish(lane, n_closest_taken, n_any_taken);
     }

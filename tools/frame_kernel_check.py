@@ -23,36 +23,44 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--time", default="1080x960:8", help="WxH:aa of the timed frame ('' = none)")
     ap.add_argument("--step-min", default="64")
+    ap.add_argument("--rebalance", default="1", help="comma list of RTAMD_OPT_FRAME_REBALANCE values for the timed frame")
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--scatter", type=int, default=1)
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
     rt = entry.load_package()
     sky = rt.load_skybox(max_width=512)
     w, h = map(int, args.cam.split("x"))
     gpu = rt.Scene.main(sky=sky, cam=(w, h)).upload(0)
-    params = dict(max_depth=args.depth, shadow_rays=1, antialiasing=args.aa)
+    params = dict(max_depth=args.depth, shadow_rays=1, antialiasing=args.aa, scatter_rays=args.scatter)
     gpu.set_option(rt.OPT_FRAME_KERNEL, 0)
     a, sa = gpu.render(**params)
     print("pipeline rendered", flush=True)
     gpu.set_option(rt.OPT_FRAME_KERNEL, 1)
-    b, sb = gpu.render(**params)
-    same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
-    print(f"{w}x{h} aa {args.aa} depth {args.depth}: identical {same}; max diff {d.max():.3e}, pixels differing {(d.max(axis=2) > 0).sum()} of {w * h}; "
-          f"rays pipeline {sa['closest_rays']} + {sa['any_rays']}, frame kernel {sb['closest_rays']} + {sb['any_rays']}; launches {sa['launches']} / {sb['launches']}", flush=True)
+    for reb in (0, 1, 2):
+        gpu.set_option(rt.OPT_FRAME_REBALANCE, reb)
+        b, sb = gpu.render(**params)
+        same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        print(f"{w}x{h} aa {args.aa} depth {args.depth} rebalance {reb}: identical {same}; max diff {d.max():.3e}, pixels differing {(d.max(axis=-1) > 0).sum()} of {w * h}; "
+              f"rays pipeline {sa['closest_rays']} + {sa['any_rays']}, frame kernel {sb['closest_rays']} + {sb['any_rays']}; launches {sa['launches']} / {sb['launches']}", flush=True)
     if not args.time:
         return
     cam, aa = args.time.split(":")
     w, h = map(int, cam.split("x"))
     aa = int(aa)
     gpu = rt.Scene.main(sky=sky, cam=(w, h)).upload(0)
-    params = dict(max_depth=args.depth, shadow_rays=1, antialiasing=aa)
+    params = dict(max_depth=args.depth, shadow_rays=1, antialiasing=aa, scatter_rays=args.scatter)
+    if args.tile:
+        params["region"] = rt.Scene.make_region(w, h, tile=(args.tile, args.tile))
     ref = None
     for mode in [0] + [1] * len(args.step_min.split(",")):
         pass
-    runs = [(0, 64)] + [(1, int(s)) for s in args.step_min.split(",")]
-    for fk, smin in runs:
+    runs = [(0, 64, 1)] + [(1, int(s), int(r)) for s in args.step_min.split(",") for r in args.rebalance.split(",")]
+    for fk, smin, reb in runs:
         gpu.set_option(rt.OPT_FRAME_KERNEL, fk)
         gpu.set_option(rt.OPT_FRAME_STEP_MIN, smin)
+        gpu.set_option(rt.OPT_FRAME_REBALANCE, reb)
         img, st = gpu.render(**params)
         best = 1e30
         for _ in range(args.reps):
@@ -62,7 +70,7 @@ def main():
         rays = st["closest_rays"] + st["any_rays"]
         if ref is None:
             ref = img
-        print(f"{w}x{h} {aa * aa} spp frame_kernel={fk} step_min={smin}: device {st['device_ms']:.2f} ms, {rays / st['device_ms'] / 1e3:.1f} Mrays/s (host {best * 1e3:.1f} ms), "
+        print(f"{w}x{h} {aa * aa} spp frame_kernel={fk} step_min={smin} rebalance={reb}: device {st['device_ms']:.2f} ms, {rays / st['device_ms'] / 1e3:.1f} Mrays/s (host {best * 1e3:.1f} ms), "
               f"rays {rays}, identical to pipeline {np.array_equal(ref.view(np.uint32), img.view(np.uint32))}", flush=True)
 
 

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--opt", default="")
     ap.add_argument("--scene", default="bunny", choices=["bunny", "spheres", "grid", "terrain", "merged", "flat"])
     ap.add_argument("--grid", type=int, default=230, help="instances per side of the grid scenes")
+    ap.add_argument("--tile", type=int, default=0, help="render as square tiles of this size (slot order is tile-major)")
+    ap.add_argument("--frame", action="store_true", help="the frame kernel (RTAMD_OPT_FRAME_KERNEL) instead of the pipeline")
     args = ap.parse_args()
     rt = entry.load_package()
     w, h = map(int, args.cam.split("x"))
@@ -33,21 +35,27 @@ def main():
             "grid": lambda: rt.Scene.grid(args.grid, args.grid, sky=sky, cam=(w, h)),
             "merged": lambda: rt.Scene.grid(args.grid, args.grid, sky=sky, cam=(w, h), flat=3), "flat": lambda: rt.Scene.grid(args.grid, args.grid, sky=sky, cam=(w, h), flat=1), "terrain": lambda: rt.Scene.terrain(300, seed=1, with_bunny=True, sky=sky, cam=(w, h))}
     scene = make[args.scene]().upload(0)
+    region = rt.Scene.make_region(w, h, tile=(args.tile, args.tile)) if args.tile else None
     opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH,
-               "ordered": rt.OPT_ORDERED_WALK, "deepen": rt.OPT_TREE_DEEPENING}
+               "ordered": rt.OPT_ORDERED_WALK, "deepen": rt.OPT_TREE_DEEPENING, "step_min": rt.OPT_FRAME_STEP_MIN, "rebalance": rt.OPT_FRAME_REBALANCE}
+    if args.frame:
+        scene.set_option(rt.OPT_FRAME_KERNEL, 1)
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
         scene.set_option(opt_ids[k], int(v))
     lib = rt.rtamd_lib()
     lib.rtamd_diag_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-    buf = (C.c_uint64 * 32)()
+    buf = (C.c_uint64 * 48)()
+    if args.frame:
+        lib.rtamd_diag_read_frame.argtypes = lib.rtamd_diag_read.argtypes
+        lib.rtamd_diag_read = lib.rtamd_diag_read_frame
     lib.rtamd_diag_read_shade.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
     sbuf = (C.c_uint64 * 32)()
     for depth in sorted({1, args.depth}):
         scene.render(max_depth=depth, antialiasing=1)  # warm up
         lib.rtamd_diag_read(scene.ctx, buf, 1)
         lib.rtamd_diag_read_shade(scene.ctx, sbuf, 1)
-        _, st = scene.render(max_depth=depth, shadow_rays=1, antialiasing=args.aa)
+        _, st = scene.render(max_depth=depth, shadow_rays=1, antialiasing=args.aa, region=region)
         lib.rtamd_diag_read(scene.ctx, buf, 1)
         lib.rtamd_diag_read_shade(scene.ctx, sbuf, 1)
         d = np.array(list(buf), dtype=np.float64)[:15].reshape(5, 3)
@@ -62,6 +70,11 @@ def main():
         for name, (cyc, cnt) in zip(("fetch: wait for staged batch", "fetch: queue-head atomic", "fetch: result stores", "obj: fold + next object", "obj: record + wrappers", "obj: mesh entry + root box", "fetch: decode + ray setup", "fetch: next-batch request"), sub):
             if cnt:
                 print(f"  {name:30s} {100 * cyc / total:5.1f}% of cycles  n {int(cnt):>10d}  cycles each {cyc / cnt:8.1f}")
+        if args.frame:
+            waves, life_sum, life_max, steps, pix, step_ticks, fetches, handed, asked, unserved = (float(x) for x in list(buf)[32:42])
+            print(f"  frame kernel: {int(waves)} waves, lifetime mean {life_sum / waves / 100:.0f} us, max {life_max / 100:.0f} us; integrator steps {int(steps)} "
+                  f"({pix / max(steps, 1):.1f} pixels each, {step_ticks / max(steps, 1) / 100:.1f} us each, {100 * step_ticks / life_sum:.1f}% of the waves' time); "
+                  f"FETCH steps {int(fetches)} ({handed / max(fetches, 1):.1f} rays handed out of {asked / max(fetches, 1):.1f} asked for, {unserved / max(fetches, 1):.1f} lanes left without)")
         sh = np.array(list(sbuf), dtype=np.float64)
         names = {0: "loads + hit reconstruction", 2: "lit-queue append", 3: "light samples", 5: "scatter", 7: "path-queue append"}
         if sh[16:].sum():
