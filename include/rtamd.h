@@ -340,11 +340,12 @@ enum rtamd_option {
                                      trees 8 beside them, 14 in scenes without meshes, 6 beside a mesh staged in LDS) of the per-lane stack
                                      an ordered walk may use; where it is full, the subtree at hand is walked in the reference's order.
                                      Same hits at any value (a test knob) */
-    RTAMD_OPT_FRAME_KERNEL = 15,  /* rtamd_render* with scatter_rays = 1: 1 the whole integrator in a few launches per 256 * waves pixels (every
-                                     wave owns a range of pixels and runs them from the first camera ray on: no chain of launches); 0 the
-                                     wavefront pipeline (a trace, a resolve and a shade launch per sample and bounce).  Same pixels, bit for
-                                     bit, same ray counts.  Scenes with more than 7 shadow rays per lit hit, max_depth = 0 and kernel
-                                     instances the mode is not built for take the pipeline */
+    RTAMD_OPT_FRAME_KERNEL = 15,  /* rtamd_render*: the frame kernel -- every wave owns a set of pixels and runs them from their first camera ray
+                                     to their last sample, tracing and shading in turn, in a handful of launches per 256 * waves pixel slots
+                                     instead of a chain of launches per sample and bounce.  0 never; 1 wherever it can run (max_depth >= 1,
+                                     at most 7 shadow rays per lit hit); 2 (default) where it is the faster form: scatter_rays != 1 on frames
+                                     of up to 1.25 Mi pixel slots (1.2-1.5 times the rate of the rounds of launches; with scatter_rays = 1 the
+                                     wavefront pipeline stays ahead by 10-15 %).  Same pixels, bit for bit, same ray counts in every mode */
     RTAMD_OPT_FRAME_STEP_MIN = 16, /* frame kernel: resumable pixels (1..64, default 64) from which a wave runs its integrator step
                                      without waiting for lanes to go idle */
     RTAMD_OPT_FRAME_REBALANCE = 17, /* frame kernel, 8 samples per pixel or more: how often (0..6, default 3) the pixel ranges of the waves are

@@ -30,7 +30,7 @@ struct rtamd_context {
     int ordered = 1;         // walks that visit the nearer child first (rt_sched.h): same three values
     uint32_t ordered_ok = 0; // ORD_MESH / ORD_TREE: the uploaded scene's trees allow them
     uint32_t ordered_cap = 15; // stack entries an ordered walk may use (RTAMD_OPT_ORDERED_STACK)
-    int frame_kernel = 0;    // RTAMD_OPT_FRAME_KERNEL
+    int frame_kernel = 2;    // RTAMD_OPT_FRAME_KERNEL: 0 never, 1 wherever it can run, 2 where it is the faster form
     int frame_step_min = 64; // RTAMD_OPT_FRAME_STEP_MIN
     int frame_rebalance = 3; // RTAMD_OPT_FRAME_REBALANCE
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
@@ -423,7 +423,10 @@ int rtamd_set_option(rtamd_context* ctx, int option, int64_t value) {
             if (value < 0 || value > 15) return fail(ctx, RTAMD_E_INVALID, "ordered stack entries must be in [0, 15]");
             ctx->ordered_cap = (uint32_t)value; ctx->S.ordered_cap = ctx->ordered_cap;
             return RTAMD_OK;
-        case RTAMD_OPT_FRAME_KERNEL: ctx->frame_kernel = value != 0 ? 1 : 0; return RTAMD_OK;
+        case RTAMD_OPT_FRAME_KERNEL:
+            if (value < 0 || value > 2) return fail(ctx, RTAMD_E_INVALID, "frame kernel mode must be 0, 1 or 2");
+            ctx->frame_kernel = (int)value;
+            return RTAMD_OK;
         case RTAMD_OPT_FRAME_STEP_MIN:
             if (value < 1 || value > 64) return fail(ctx, RTAMD_E_INVALID, "frame step threshold must be in [1, 64]");
             ctx->frame_step_min = (int)value;
@@ -1108,6 +1111,7 @@ int render_depth_first_rounds(rtamd_context* ctx, const rtamd_camera* cam, const
 // 256 * waves pixel slots one seeding launch, then one launch per window of the pixels' samples: [0, 1) over ranges of equal
 // length, then [1, 4), [4, 16), [16, ...) (as many as RTAMD_OPT_FRAME_REBALANCE says), each with the units of 64 pixel slots dealt
 // to the waves for equal cost by what the window before it measured.
+static constexpr size_t FRAME_KERNEL_AUTO_SLOTS = 1310720;   // 1.25 Mi pixel slots
 int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, size_t total_slots,
                         uint32_t S_total, uint32_t S_shoot, float* out, rtamd_stats* stats) {
     const uint32_t n_waves = mega_waves(ctx->S, ctx->cfg);
@@ -1119,7 +1123,7 @@ int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     WaveBufs W = ws.W;
     W.cap = (uint32_t)ws.cap;
     hipStream_t st = ws.stream;
-    const size_t park_words = (size_t)48 * 64 * n_waves, range_words = (size_t)n_waves * 7, group_words = cap / 64 + 1;
+    const size_t park_words = (size_t)48 * 64 * n_waves, range_words = (size_t)n_waves * mega_banks(), group_words = cap / 64 + 1;
     const bool tree = integ->scatter_rays != 1;
     const size_t stack_words = tree ? (size_t)integ->max_depth * 20 * ws.cap : 0;
     rc = ensure_batch(ctx, (park_words + range_words + 2 * group_words + 2 * (size_t)n_waves + stack_words) * 4);
@@ -1167,7 +1171,7 @@ int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                 HIP_TRY(ctx, hipMemcpyAsync(ticks.data(), F.wave_scale + n_waves, (size_t)n_waves * 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(ctx, hipStreamSynchronize(st));
                 double sum = 0; uint32_t mx = 0, used = 0, most = 0, argmax = 0;
-                auto held = [&](uint32_t w) { uint32_t n = 0; for (uint32_t q = 0; q < 7; q++) n += units[(size_t)w * 7 + q] != 0xFFFFFFFFu; return n; };
+                auto held = [&](uint32_t w) { uint32_t n = 0; for (uint32_t q = 0; q < mega_banks(); q++) n += units[(size_t)w * mega_banks() + q] != 0xFFFFFFFFu; return n; };
                 for (uint32_t w = 0; w < n_waves; w++) {
                     const uint32_t n = held(w);
                     if (!n) continue;
@@ -1243,12 +1247,15 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     if (integ->scatter_rays != 1) {
         // the round pipeline needs a ray per pixel to start with (max_depth >= 1); RTAMD_OPT_DEPTH_FIRST_ROUNDS = 0 selects
         // the one-lane-per-pixel kernel
-        if (ctx->frame_kernel && integ->max_depth >= 1 && integ->max_depth <= 255 && S_shoot <= 7 && mega_supported(ctx->S, ctx->cfg))
+        // (measured, rt_mega.hip: branching scatter rays run 1.2-1.5 times faster in the frame kernel than in rounds of launches
+        // while a frame is about one chunk of it; larger frames fill the rounds' launches and the rounds win)
+        const bool pays = ctx->frame_kernel == 1 || (ctx->frame_kernel == 2 && total_slots <= FRAME_KERNEL_AUTO_SLOTS);
+        if (pays && integ->max_depth >= 1 && integ->max_depth <= 255 && S_shoot <= 7 && mega_supported(ctx->S, ctx->cfg))
             return render_frame_kernel(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
         if (ctx->df_rounds && integ->max_depth >= 1) return render_depth_first_rounds(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
         return render_depth_first(ctx, cam, integ, region, total_slots, out, stats);
     }
-    if (ctx->frame_kernel && integ->max_depth >= 1 && S_shoot <= 7 && mega_supported(ctx->S, ctx->cfg))
+    if (ctx->frame_kernel == 1 && integ->max_depth >= 1 && S_shoot <= 7 && mega_supported(ctx->S, ctx->cfg))   // (on request only: the pipeline is faster)
         return render_frame_kernel(ctx, cam, integ, region, total_slots, S_total, S_shoot, out, stats);
     // pixel groups: at most n_streams in flight, none smaller than 64 Ki pixels unless the region is
     const size_t G = (size_t)ctx->n_streams;

@@ -184,7 +184,7 @@ struct MegaFrame {
     uint32_t step_min;   // resumable pixels of a wave from which its integrator step runs without waiting for idle lanes (1..64)
     float* out;
     uint32_t* park;      // 48 * 64 * mega_waves() words of scratch (lane state parked around the integrator step)
-    uint32_t* units;     // 7 words per wave (device): mega_assign
+    uint32_t* units;     // mega_banks() words per wave (device): mega_assign
     uint32_t* owner;     // one word per unit of 64 slots (device): mega_assign
     uint32_t* group_cost;   // one word (a float) per unit (device)
     int32_t scatter_rays;   // != 1: one launch_mega over all samples; needs `stack`
@@ -192,12 +192,13 @@ struct MegaFrame {
     uint32_t* wave_scale;   // 2 * mega_waves() words (device)
 };
 uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg);
+uint32_t mega_banks();   // units of 64 pixel slots a wave can hold
 bool mega_supported(const DevScene& S, const LaunchCfg& cfg);
 hipError_t launch_mega_init(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, hipStream_t st);
 hipError_t launch_mega(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, uint32_t s_begin,
                        uint32_t s_end, hipStream_t st);
 hipError_t launch_mega_group_cost(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_n, hipStream_t st);
-// cost: host copy of F.group_cost (null: the first deal); units: 7 * mega_waves() words, owner: one per unit (host)
+// cost: host copy of F.group_cost (null: the first deal); units: mega_banks() * mega_waves() words, owner: one per unit (host)
 void mega_assign(const float* cost, uint32_t chunk_n, uint32_t n_waves, uint32_t* units, uint32_t* owner);
 hipError_t launch_quantize(const float* rgb, size_t n, uint8_t* out, hipStream_t st);
 // The reference's binned-SAH tree over n boxes (6 floats each, device memory), built on the GPU (rt_bvh.hip).

@@ -16,7 +16,7 @@
 
 namespace rtamd {
 
-// A wave owns up to seven units of 64 consecutive pixel slots of the chunk (neighbouring pixels: rays that walk the scene alike
+// A wave owns up to five units of 64 consecutive pixel slots of the chunk (neighbouring pixels: rays that walk the scene alike
 // keep a wave's lanes in the same phases), named by a table.  The units are dealt for equal cost, not equal number: a launch
 // covers a window of the pixels' samples, counts the rays of every pixel and clocks every wave, and the host deals the next
 // window's units by those costs (launch_mega / mega_assign), because a wave that owned 256 pixels of sky would be done in a
@@ -135,6 +135,18 @@ __device__ __attribute__((noinline)) uint32_t pixel_step(const uint64_t params, 
     float* Lp = W.Lb[0];
     f3 L = mk(Lp[j], Lp[j + cap], Lp[j + 2 * cap]);
     f3 beta = mk(W.beta[j], W.beta[j + cap], W.beta[j + 2 * cap]);
+    // everything the step reads whatever the pixel's state is requested here, in one round trip (a step is a chain of dependent
+    // loads, and the whole wave waits for it)
+    const float* r = W.q_ray[0];
+    const f3 pos = mk(r[j], r[j + cap], r[j + 2 * cap]);
+    const f3 dir = mk(r[j + 3 * cap], r[j + 4 * cap], r[j + 5 * cap]);
+    const uint4 rec0 = W.h_rec[2 * (size_t)j];
+    const float rec1 = __uint_as_float(W.h_rec[2 * (size_t)j + 1].x);
+    Rng rng;
+    rng.lo = W.rng_lo[j]; rng.hi = W.rng_hi[j];
+    const f3 sum_in = mk(W.sum[j], W.sum[j + cap], W.sum[j + 2 * cap]);
+    const DevObject ob_hit = S.objects[rec0.x < S.n_objects ? rec0.x : 0u];
+    asm volatile("" ::: "memory");   // (the loads stay up here)
     // ---- the lit hit whose shadow rays have returned (illumination(), integrator.rs:107-132; :87) ----
     if (meta & PM_LIT) {
         const float* f = T.lit_f;
@@ -188,31 +200,27 @@ __device__ __attribute__((noinline)) uint32_t pixel_step(const uint64_t params, 
     // ---- a finished sample joins the pixel's sum (integrator.rs:50-53) ----
     f3 sum = mk(0, 0, 0);
     if (meta & (PM_NEWS | PM_FINAL)) {
-        sum = mk(W.sum[j], W.sum[j + cap], W.sum[j + 2 * cap]) + L;
+        sum = sum_in + L;
         L = fill(0.0f);
         beta = fill(1.0f);
         if (meta & PM_FINAL) return leave(sum, sample);
         W.sum[j] = sum.x; W.sum[j + cap] = sum.y; W.sum[j + 2 * cap] = sum.z;
     }
     // ---- the hit of the ray that has returned (integrate_recur, integrator.rs:66-102) ----
-    const float* r = W.q_ray[0];
-    const f3 pos = mk(r[j], r[j + cap], r[j + 2 * cap]);
-    const f3 dir = mk(r[j + 3 * cap], r[j + 4 * cap], r[j + 5 * cap]);
     bool lit = false, cont = false;
     f3 next_pos = mk(0, 0, 0), next_dir = mk(0, 0, 0);
     Best b;
-    const uint4 rec0 = W.h_rec[2 * (size_t)j];
     b.obj = rec0.x;
     if (b.obj != MISS && b.obj >= S.n_objects) { W.stats[2] = 4u; b.obj = MISS; }   // (cannot happen: a record no trace has written)
     if (b.obj == MISS) {  // integrator.rs:66
         L = L + beta * sky_color(S, dir);
     } else {
         b.prim = rec0.y;
-        b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = __uint_as_float(W.h_rec[2 * (size_t)j + 1].x);
+        b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = rec1;
         f3 hp, hn;
         float hu, hv;
         reconstruct_hit(S, b, pos, dir, hp, hn, hu, hv);
-        const uint32_t mat = S.objects[b.obj].material;
+        const uint32_t mat = ob_hit.material;
         const f3 nrm = normalize(hn);                                  // integrator.rs:72-76
         const bool outside = dot(nrm, -dir) > 0.0f;
         const f3 p_out = hp + nrm * 0.001f, p_in = hp - nrm * 0.001f;
@@ -220,8 +228,6 @@ __device__ __attribute__((noinline)) uint32_t pixel_step(const uint64_t params, 
         const DevMaterial m = S.materials[mat];
         const f3 diffuse = material_diffuse(S, m, hu, hv);
         lit = !is_zero(diffuse);                                       // integrator.rs:80
-        Rng rng;
-        rng.lo = W.rng_lo[j]; rng.hi = W.rng_hi[j];
         if (lit) {                                                     // integrator.rs:80-88
             float* f = T.lit_f;
             f[j] = beta.x; f[j + cap] = beta.y; f[j + 2 * cap] = beta.z;
@@ -282,7 +288,7 @@ __device__ __attribute__((noinline)) uint32_t pixel_step(const uint64_t params, 
         } else if (lit) {
             flags |= PM_FINAL;
         } else {   // nothing in flight: the pixel leaves here and now
-            return leave(mk(W.sum[j], W.sum[j + cap], W.sum[j + 2 * cap]) + L, sample);
+            return leave(((meta & PM_NEWS) ? sum : sum_in) + L, sample);
         }
     }
     if (ray) {
@@ -648,6 +654,8 @@ hipError_t mega_diag_read(unsigned long long* out48, int reset) {
 }
 #endif
 
+uint32_t mega_banks() { return MEGA_BANKS; }
+
 uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg) {
     const bool no_mesh = S.n_meshes == 0;
     const int per_cu = no_mesh ? (cfg.sched_blocks_per_cu * NOMESH_WAVES_PER_SIMD + SCHED_WAVES_PER_SIMD - 1) / SCHED_WAVES_PER_SIMD : cfg.sched_blocks_per_cu;
@@ -661,13 +669,8 @@ static MegaParams mega_params(const DevScene& S, const LaunchCfg& cfg, const Wav
 }
 
 bool mega_supported(const DevScene& S, const LaunchCfg& cfg) {
-#ifdef RTAMD_MEGA_ALL
-    return true;
-#else
-    // (development build: the instance of a scene with one small mesh only)
-    const int tab = !cfg.use_lds ? TAB_GLOBAL : (S.tab_bytes > 0 ? TAB_LDS : (S.mid_bytes > 0 ? TAB_MID : TAB_GLOBAL));
-    return mesh_location(S, cfg) == MESH_LDS && tab == TAB_LDS;
-#endif
+    (void)S;
+    return cfg.scheduler != 0;   // (the frame kernel is the scheduler kernel with a pool in place of the queue)
 }
 
 hipError_t launch_mega_init(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n, hipStream_t st) {
@@ -691,15 +694,7 @@ hipError_t launch_mega(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& 
     if (!mega_supported(S, cfg)) return hipErrorNotSupported;
     const MegaParams P = mega_params(S, cfg, W, F, chunk_begin, chunk_n, s_begin, s_end);
     const uint32_t g = n_waves / (TRACE_BLOCK / 64);
-#ifdef RTAMD_MEGA_ALL
     RTAMD_DISPATCH_MESHLOC(S, cfg, k_mega, g, st, P);
-#else
-    {
-        const uint32_t lb_ = S.lds_sched_bytes + S.tab_bytes;
-        const bool lean_ = cfg.lean && (S.features & ~sched_features(MESH_LDS, true)) == 0u;
-        RTAMD_DISPATCH_LEAN(k_mega, MESH_LDS, TAB_LDS, lean_, g, lb_, st, P);
-    }
-#endif
     return hipGetLastError();
 }
 

@@ -142,7 +142,7 @@ static __device__ unsigned long long g_diag[48];
 #define DIAG_SUB_BEGIN unsigned long long d_s0 = __builtin_amdgcn_s_memtime();
 #define DIAG_SUB_END(slot) { d_sub[slot] += __builtin_amdgcn_s_memtime() - d_s0; d_subn[slot] += 1; }
 #define DIAG_SUB_MARK d_s0 = __builtin_amdgcn_s_memtime();
-#define DIAG_FLUSH if (IO::MEGA && lane == 0) { const unsigned long long life = __builtin_amdgcn_s_memtime() - d_born; atomicAdd(&g_diag[32], 1ull); atomicAdd(&g_diag[33], life); atomicMax(&g_diag[34], life); for (int q = 0; q < 8; q++) atomicAdd(&g_diag[35 + q], d_pool[q]); } if (lane == 0) { for (int q = 0; q < 8; q++) { atomicAdd(&g_diag[15 + 2 * q], d_sub[q]); atomicAdd(&g_diag[16 + 2 * q], d_subn[q]); } } if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
+#define DIAG_FLUSH if (IO::MEGA && lane == 0) { const unsigned long long life = __builtin_amdgcn_s_memtime() - d_born; atomicAdd(&g_diag[32], 1ull); atomicAdd(&g_diag[33], life); atomicMax(&g_diag[34], life); for (int q = 0; q < 12; q++) atomicAdd(&g_diag[35 + q], d_pool[q]); } if (lane == 0) { for (int q = 0; q < 8; q++) { atomicAdd(&g_diag[15 + 2 * q], d_sub[q]); atomicAdd(&g_diag[16 + 2 * q], d_subn[q]); } } if (lane == 0) { for (int q = 0; q < 5; q++) { atomicAdd(&g_diag[q * 3], d_cyc[q]); atomicAdd(&g_diag[q * 3 + 1], d_steps[q]); atomicAdd(&g_diag[q * 3 + 2], d_lanes[q]); } }
 #else
 #define DIAG_DECL unsigned long long* const d_pool = nullptr;
 #define DIAG_TOP
@@ -433,22 +433,26 @@ __host__ __device__ constexpr uint32_t sched_features(int meshloc, bool lean) {
 // CU; beside a mesh staged in LDS three entries fit (rtamd_upload_scene keeps mesh + tables within what is left).  Scenes whose
 // tables fit LDS (at most 64 objects) have no tree worth an ordered walk.
 // ------------------------------------------------------------------------------------------------
-// Per-frame form (IO::MEGA): a wave owns up to 448 pixels for a whole launch and does everything for them.  Its lanes trace
+// Per-frame form (IO::MEGA): a wave owns up to 320 pixels for a whole launch and does everything for them.  Its lanes trace
 // the rays of those pixels; whenever all rays a pixel waits for have returned, the pixel is resumable, and the wave's
 // FETCH step runs the integrator for up to 64 resumable pixels at once (io.step: shade the hit, draw the light samples
 // and the scatter direction, start the pixel's next sample), which leaves new rays ready.  Nothing is shared between
 // waves, so there is nothing to wait for and no launch boundary between the bounces of a path or the samples of a pixel.
 //
 // State of pixel p of the wave, one LDS word (io.pix[p]):
-// (every lane looks after 7 of them in the scans below: 64 x 7 words + 64 words of list = the 2 KB of the ray staging buffer)
+// (every lane looks after POOL_PER_LANE = 5 of them in the scans below -- 7 would fit the 2 KB the pool takes over from the ray staging
+// buffer, but the scans cost more than the room returns: headline frame 64.6 against 66.2 ms)
 //   bits 0-7   rays ready to be traced (bit 0 the closest-hit ray, bit k the k-th shadow ray)
 //   bits 8-11  rays handed out or ready whose results have not come back
 //   bit  12    the pixel has samples left
 //   bits 16-31 index of the sample the pixel works on
-// A ray is named by ref = p << 3 | k.  io.pix[448 .. 511] is scratch for the lists built here.
+// A ray is named by ref = p << 3 | k.  io.pix[POOL_PIXELS .. POOL_PIXELS + 63] is scratch for the lists built here.
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t PW_RDY_MASK = 0xFFu, PW_PEND_ONE = 0x100u, PW_PEND_MASK = 0xF00u, PW_ALIVE = 0x1000u, PW_SAMPLE_SHIFT = 16u;
-static constexpr uint32_t POOL_PER_LANE = 7u;   // pixels a lane looks after in the FETCH step's scans
+#ifndef RTAMD_POOL_PER_LANE
+#define RTAMD_POOL_PER_LANE 5
+#endif
+static constexpr uint32_t POOL_PER_LANE = RTAMD_POOL_PER_LANE;   // pixels a lane looks after in the FETCH step's scans (at most 7: the pool's LDS)
 static constexpr uint32_t POOL_PIXELS = 64u * POOL_PER_LANE, POOL_WORDS = POOL_PIXELS + 64u;
 #ifndef RTAMD_POOL_AHEAD
 #define RTAMD_POOL_AHEAD 0
@@ -524,7 +528,9 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
         t_rdy = tot & 0x1FFFu; t_res = (tot >> 13) & 0x1FFu; t_alive = tot >> 22;
         tA_rdy = totA & 0x1FFFu; tA_res = (totA >> 13) & 0x1FFu;
     };
+    POOL_DIAG(unsigned long long pt = __builtin_amdgcn_s_memtime();)
     scan();
+    POOL_DIAG({ const unsigned long long n = __builtin_amdgcn_s_memtime(); dp[7] += n - pt; pt = n; })
     // (3) resumable pixels: run the integrator for them when there are enough to fill the wave, or when lanes would
     // otherwise go without a ray
     if (t_res > 0u && (t_res >= io.step_min || t_rdy < c_want)) {
@@ -549,6 +555,7 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
         if (act) pix[p] = nw;
         asm volatile("" ::: "memory");
         scan();
+        POOL_DIAG({ const unsigned long long n = __builtin_amdgcn_s_memtime(); dp[8] += n - pt; pt = n; })
     }
     // (4) ready rays to the lanes that want one
     const uint32_t take = c_want < t_rdy ? c_want : t_rdy;
@@ -575,6 +582,7 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
         const unsigned long long served = __ballot(any_handed);
         rot = (rot + 63u - (uint32_t)__builtin_clzll(served)) & 63u;
     }
+    POOL_DIAG({ const unsigned long long n = __builtin_amdgcn_s_memtime(); dp[9] += n - pt; pt = n; })
     const bool got = want && wrank < take;
     uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (got) {
@@ -591,6 +599,7 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
         // resumable pixels are left it keeps asking, so that the step for them comes even if no ray is in flight
         st = t_alive == 0u ? ST_DONE : (t_res > 0u ? ST_FETCH : ST_IDLE);
     }
+    POOL_DIAG({ asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long n = __builtin_amdgcn_s_memtime(); dp[10] += n - pt; })
     POOL_DIAG(dp[3] += 1; dp[4] += take; dp[5] += c_want; dp[6] += c_want - take;)
     const unsigned long long got_any = __ballot(got && (ridx & 7u) != 0u);
     n_any += (uint32_t)__builtin_popcountll(got_any);

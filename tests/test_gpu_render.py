@@ -91,12 +91,14 @@ def test_depth_first_rounds_equal_the_one_lane_kernel(rt, pair, params):
     """scatter_rays != 1 has two forms: rounds of one scheduler launch over every pixel's next ray (default) and one lane
     per pixel with nested loops.  Same operations per pixel in the same order: same bits, same ray counts."""
     gpu, _, _ = pair
+    gpu.set_option(rt.OPT_FRAME_KERNEL, 0)    # (a frame this small would otherwise take the frame kernel: test_gpu_frame_kernel.py)
     img, st = gpu.render(**params)
     gpu.set_option(rt.OPT_DEPTH_FIRST_ROUNDS, 0)
     try:
         ref, st0 = gpu.render(**params)
     finally:
         gpu.set_option(rt.OPT_DEPTH_FIRST_ROUNDS, 1)
+        gpu.set_option(rt.OPT_FRAME_KERNEL, 2)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert (st["closest_rays"], st["any_rays"]) == (st0["closest_rays"], st0["any_rays"])
     assert st["launches"] > st0["launches"]
@@ -190,6 +192,7 @@ def test_depth_first_rounds_in_chunks_smaller_than_an_earlier_workspace(rt, sky)
     params = dict(max_depth=3, shadow_rays=1, scatter_rays=2, antialiasing=2)
     ref, st0 = rt.Scene.main(sky=sky, cam=(128, 96)).upload(0).render(**params)   # one chunk, a context of its own
     gpu = rt.Scene.main(sky=sky, cam=(128, 96)).upload(0)
+    gpu.set_option(rt.OPT_FRAME_KERNEL, 0)                                        # (the rounds of launches are what is tested)
     gpu.render(max_depth=2, shadow_rays=1, scatter_rays=1, antialiasing=1)        # wavefront render: a workspace for the whole frame
     gpu.set_option(rt.OPT_MAX_PATHS, 2500)
     img, st = gpu.render(**params)                                                # five chunks in that workspace

@@ -26,12 +26,15 @@ def main():
     ap.add_argument("--rebalance", default="1", help="comma list of RTAMD_OPT_FRAME_REBALANCE values for the timed frame")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--scatter", type=int, default=1)
+    ap.add_argument("--scene", default="main", choices=["main", "spheres", "grid", "textured"])
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
     rt = entry.load_package()
     sky = rt.load_skybox(max_width=512)
     w, h = map(int, args.cam.split("x"))
-    gpu = rt.Scene.main(sky=sky, cam=(w, h)).upload(0)
+    make = {"main": lambda cam: rt.Scene.main(sky=sky, cam=cam), "spheres": lambda cam: rt.Scene.spheres(n=10000, seed=1, sky=sky, cam=cam),
+            "grid": lambda cam: rt.Scene.grid(60, 60, sky=sky, cam=cam), "textured": lambda cam: rt.Scene.textured(sky=sky, cam=cam)}[args.scene]
+    gpu = make((w, h)).upload(0)
     params = dict(max_depth=args.depth, shadow_rays=1, antialiasing=args.aa, scatter_rays=args.scatter)
     gpu.set_option(rt.OPT_FRAME_KERNEL, 0)
     a, sa = gpu.render(**params)
@@ -49,7 +52,7 @@ def main():
     cam, aa = args.time.split(":")
     w, h = map(int, cam.split("x"))
     aa = int(aa)
-    gpu = rt.Scene.main(sky=sky, cam=(w, h)).upload(0)
+    gpu = make((w, h)).upload(0)
     params = dict(max_depth=args.depth, shadow_rays=1, antialiasing=aa, scatter_rays=args.scatter)
     if args.tile:
         params["region"] = rt.Scene.make_region(w, h, tile=(args.tile, args.tile))

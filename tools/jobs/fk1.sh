@@ -1,7 +1,9 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 200 python -u tools/frame_kernel_check.py --cam 256x192 --aa 3 --scatter 2 --time "" 2>&1 | tee gpurun_out/fk1.txt
-if grep -q "identical False" gpurun_out/fk1.txt; then exit 1; fi
-timeout -k 10 200 python -u tools/frame_kernel_check.py --cam 200x150 --aa 1 --scatter 2 --time "1080x960:2" --rebalance 0,1,2 --reps 2 2>&1 | tee gpurun_out/fk3.txt
-timeout -k 10 200 python -u tools/frame_kernel_check.py --cam 200x150 --aa 1 --scatter 2 --time "1080x960:4" --rebalance 0,2,3 --reps 2 2>&1 | tee gpurun_out/fk4.txt
+rm -f gpurun_out/fk_var.txt
+for v in "" variants/librtamd_ahead1.so variants/librtamd_ahead3.so variants/librtamd_ahead64.so variants/librtamd_ppl5.so; do
+echo "== ${v:-product}" | tee -a gpurun_out/fk_var.txt
+if [ -n "$v" ]; then export RTAMD_LIB=rust-raytracer_amd/$v; fi
+timeout -k 10 300 python -u tools/frame_kernel_check.py --cam 160x120 --aa 3 --time "1080x960:8" --rebalance 2 --step-min 64,40 --reps 2 2>&1 | grep "rebalance 2\|spp frame\|rror" | tee -a gpurun_out/fk_var.txt
+done

@@ -75,6 +75,9 @@ def main():
             print(f"  frame kernel: {int(waves)} waves, lifetime mean {life_sum / waves / 100:.0f} us, max {life_max / 100:.0f} us; integrator steps {int(steps)} "
                   f"({pix / max(steps, 1):.1f} pixels each, {step_ticks / max(steps, 1) / 100:.1f} us each, {100 * step_ticks / life_sum:.1f}% of the waves' time); "
                   f"FETCH steps {int(fetches)} ({handed / max(fetches, 1):.1f} rays handed out of {asked / max(fetches, 1):.1f} asked for, {unserved / max(fetches, 1):.1f} lanes left without)")
+            t_scan, t_step, t_hand, t_load = (float(x) for x in list(buf)[42:46])
+            print(f"  FETCH step, share of the waves' time: first scan {100 * t_scan / life_sum:.1f}%, integrator step with lists and second scan {100 * t_step / life_sum:.1f}%, "
+                  f"hand-out {100 * t_hand / life_sum:.1f}%, ray loads + result stores + ray setup {100 * t_load / life_sum:.1f}%")
         sh = np.array(list(sbuf), dtype=np.float64)
         names = {0: "loads + hit reconstruction", 2: "lit-queue append", 3: "light samples", 5: "scatter", 7: "path-queue append"}
         if sh[16:].sum():
