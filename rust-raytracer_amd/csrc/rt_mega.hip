@@ -117,6 +117,9 @@ __device__ __forceinline__ T load_const(const_words src) {
     for (uint32_t k = 0; k < sizeof(T) / 4; k++) d[k] = src[k];
     return t;
 }
+// (WAVES: the waves per SIMD of the calling kernel.  A function shared by kernels of different register budgets is compiled for the
+// tightest of them -- the 80 registers of the mesh-free kernels cost the others a quarter of their rate -- so each budget gets its own.)
+template <int WAVES>
 __device__ __attribute__((noinline)) uint32_t pixel_step(const uint64_t params, const uint32_t j, const uint32_t active) {
     if (!active) return 0u;
     // (the builtin returns a signed int: without the casts the low half would be sign-extended over the high one)
@@ -341,6 +344,7 @@ __device__ __forceinline__ void tree_frame_load(const float* stack, size_t cap, 
 }
 enum : uint32_t { TS_ENTER = 0, TS_SCATTER = 1, TS_FOLD = 2 };
 
+template <int WAVES>
 __device__ __attribute__((noinline)) uint32_t pixel_step_tree(const uint64_t params, const uint32_t slot, const uint32_t active) {
     if (!active) return 0u;
     const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(params >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)params);
@@ -363,12 +367,21 @@ __device__ __attribute__((noinline)) uint32_t pixel_step_tree(const uint64_t par
     uint32_t pend = 0;
     Rng rng;
     rng.lo = W.rng_lo[slot]; rng.hi = W.rng_hi[slot];
+    // what most steps read is requested here, in one round trip with the state words (the whole wave waits for a step, and a step
+    // is a chain of dependent loads)
+    const float* r_in = W.q_ray[0];
+    const f3 ray_pos = mk(r_in[slot], r_in[slot + cap], r_in[slot + 2 * cap]);
+    const f3 ray_dir = mk(r_in[slot + 3 * cap], r_in[slot + 4 * cap], r_in[slot + 5 * cap]);
+    const uint4 rec0 = W.h_rec[2 * (size_t)slot];
+    const float rec1 = __uint_as_float(W.h_rec[2 * (size_t)slot + 1].x);
+    const f3 df_in = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
+    asm volatile("" ::: "memory");   // (the loads stay up here)
     TreeFrame f;
     f.color = f.w = f.n = f.dir = f.p_out = f.p_in = fill(0.0f); f.mat = 0; f.k = 0;
     f3 ret = fill(0.0f), rpos = fill(0.0f), rdir = mk(0, 0, 1), diffuse = fill(0.0f), p_lit = fill(0.0f);
     bool lit = false, in_scatter = false, in_return = false;
     if (pend_in) {   // the shadow rays of the pixel's last hit are back: illumination(), integrator.rs:107-132, then :87
-        const f3 df = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
+        const f3 df = df_in;
         f3 illum = fill(0.0f);
         uint32_t s = 0;
         for (uint32_t l = 0; l < S.n_lights; l++) {
@@ -387,10 +400,8 @@ __device__ __attribute__((noinline)) uint32_t pixel_step_tree(const uint64_t par
         q[0] = c.x; q[cap] = c.y; q[2 * (size_t)cap] = c.z;   // (the frame's colour: its first three words)
     }
     if (state == TS_ENTER) {               // the closest-hit ray of integrate_recur(ray, d) is back, integrator.rs:64
-        const float* r_in = W.q_ray[0];
-        rpos = mk(r_in[slot], r_in[slot + cap], r_in[slot + 2 * cap]);
-        rdir = mk(r_in[slot + 3 * cap], r_in[slot + 4 * cap], r_in[slot + 5 * cap]);
-        const uint4 rec0 = W.h_rec[2 * (size_t)slot];
+        rpos = ray_pos;
+        rdir = ray_dir;
         if (rec0.x != MISS && rec0.x >= S.n_objects) W.stats[2] = 4u;   // (cannot happen: a record no trace has written)
         if (rec0.x == MISS || rec0.x >= S.n_objects) {              // integrator.rs:66
             ret = sky_color(S, rdir);
@@ -398,7 +409,7 @@ __device__ __attribute__((noinline)) uint32_t pixel_step_tree(const uint64_t par
         } else {
             Best b;
             b.obj = rec0.x; b.prim = rec0.y;
-            b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = __uint_as_float(W.h_rec[2 * (size_t)slot + 1].x);
+            b.t_local = __uint_as_float(rec0.z); b.u = __uint_as_float(rec0.w); b.v = rec1;
             f3 hp, hn;
             float hu, hv;
             reconstruct_hit(S, b, rpos, rdir, hp, hn, hu, hv);
@@ -531,6 +542,7 @@ __device__ __attribute__((noinline)) uint32_t pixel_step_tree(const uint64_t par
     return PW_ALIVE | rdy | (((want_ray ? 1u : 0u) + n_shadow) << 8) | ((pass & 0xFFFFu) << PW_SAMPLE_SHIFT);
 }
 
+template <int WAVES>
 struct MegaIO {
     static constexpr bool MEGA = true;
     const float* q_ray;
@@ -582,7 +594,7 @@ struct MegaIO {
     __device__ __forceinline__ void store_any(uint32_t, uint32_t tag, bool occluded) const { vis[tag] = occluded ? 1 : 0; }
     __device__ __forceinline__ uint32_t slot(uint32_t p) const { return unit_tab[p >> 6] * MEGA_GROUP + (p & 63u); }
     __device__ __forceinline__ uint32_t step(uint32_t p, bool active) const {
-        return tree ? pixel_step_tree(params, slot(p), active ? 1u : 0u) : pixel_step(params, slot(p), active ? 1u : 0u);
+        return tree ? pixel_step_tree<WAVES>(params, slot(p), active ? 1u : 0u) : pixel_step<WAVES>(params, slot(p), active ? 1u : 0u);
     }
     __device__ __forceinline__ void fail(uint32_t lane, uint32_t code) const {
         if (lane == 0u) stats[2] = code;
@@ -634,7 +646,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
         count += go ? 1u : 0u;
     }
     count = __builtin_amdgcn_readlane(wave_scan_add(count), 63);
-    MegaIO io{P.W.q_ray[0], P.W.set[0].a_ray, P.W.set[0].a_vidx, P.W.h_rec, P.W.set[0].vis, (unsigned long long*)P.W.stats, P.W.cap, P.W.any_cap, unit_tab, P.step_min,
+    MegaIO<(MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD)> io{P.W.q_ray[0], P.W.set[0].a_ray, P.W.set[0].a_vidx, P.W.h_rec, P.W.set[0].vis, (unsigned long long*)P.W.stats, P.W.cap, P.W.any_cap, unit_tab, P.step_min,
               (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(), P.park, (size_t)P.n_waves * 64u, P.wave_scale + wave_id, count, P.n_waves, P.scatter_rays != 1, pool};
     if (lane == 0u) P.wave_scale[wave_id] = (uint32_t)__builtin_amdgcn_s_memtime();
     if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, nullptr, 0u, 64u, pool, coop, ostack);

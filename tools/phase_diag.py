@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--scene", default="bunny", choices=["bunny", "spheres", "grid", "terrain", "merged", "flat"])
     ap.add_argument("--grid", type=int, default=230, help="instances per side of the grid scenes")
     ap.add_argument("--tile", type=int, default=0, help="render as square tiles of this size (slot order is tile-major)")
+    ap.add_argument("--scatter", type=int, default=1)
     ap.add_argument("--frame", action="store_true", help="the frame kernel (RTAMD_OPT_FRAME_KERNEL) instead of the pipeline")
     args = ap.parse_args()
     rt = entry.load_package()
@@ -55,7 +56,7 @@ def main():
         scene.render(max_depth=depth, antialiasing=1)  # warm up
         lib.rtamd_diag_read(scene.ctx, buf, 1)
         lib.rtamd_diag_read_shade(scene.ctx, sbuf, 1)
-        _, st = scene.render(max_depth=depth, shadow_rays=1, antialiasing=args.aa, region=region)
+        _, st = scene.render(max_depth=depth, shadow_rays=1, antialiasing=args.aa, region=region, scatter_rays=args.scatter)
         lib.rtamd_diag_read(scene.ctx, buf, 1)
         lib.rtamd_diag_read_shade(scene.ctx, sbuf, 1)
         d = np.array(list(buf), dtype=np.float64)[:15].reshape(5, 3)
