@@ -32,7 +32,7 @@ struct rtamd_context {
     uint32_t ordered_cap = 15; // stack entries an ordered walk may use (RTAMD_OPT_ORDERED_STACK)
     int frame_kernel = 2;    // RTAMD_OPT_FRAME_KERNEL: 0 never, 1 wherever it can run, 2 where it is the faster form
     int frame_step_min = 64; // RTAMD_OPT_FRAME_STEP_MIN
-    int frame_rebalance = 3; // RTAMD_OPT_FRAME_REBALANCE
+    int frame_rebalance = 0; // RTAMD_OPT_FRAME_REBALANCE
     bool df_rounds = true;   // scatter_rays != 1: rounds of scheduler-kernel launches (false: one lane per pixel, nested loops)
     size_t max_paths = (size_t)1 << 25;   // pixel slots per wavefront chunk: 33.5 M slots (an 8K frame in one chunk), about 470 B each at 3 light samples
 
