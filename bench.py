@@ -262,7 +262,8 @@ def main():
     scene.upload(dev_index)
     upload_s = time.perf_counter() - t0
     opt_ids = {"chunk": rt.OPT_CHUNK, "blocks": rt.OPT_BLOCKS_PER_CU, "lds": rt.OPT_LDS_SCENE, "max_paths": rt.OPT_MAX_PATHS, "streams": rt.OPT_STREAMS, "static": rt.OPT_STATIC_SHARE, "min_batch": rt.OPT_MIN_BATCH, "lean": rt.OPT_LEAN_KERNELS,
-               "ordered": rt.OPT_ORDERED_WALK, "deepen": rt.OPT_TREE_DEEPENING, "ostack": rt.OPT_ORDERED_STACK}
+               "ordered": rt.OPT_ORDERED_WALK, "deepen": rt.OPT_TREE_DEEPENING, "ostack": rt.OPT_ORDERED_STACK,
+               "frame": rt.OPT_FRAME_KERNEL, "rebalance": rt.OPT_FRAME_REBALANCE, "step_min": rt.OPT_FRAME_STEP_MIN}
     for kv in filter(None, args.opt.split(",")):
         k, v = kv.split("=")
         scene.set_option(opt_ids[k], int(v))
