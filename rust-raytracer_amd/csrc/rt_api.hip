@@ -1123,16 +1123,17 @@ int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     WaveBufs W = ws.W;
     W.cap = (uint32_t)ws.cap;
     hipStream_t st = ws.stream;
-    const size_t park_words = (size_t)48 * 64 * n_waves, range_words = (size_t)n_waves * mega_banks(), group_words = cap / 64 + 1;
+    // one scratch buffer: [units of the waves | owner of every unit | cost of every unit | 2 words per wave | path frames]
+    const size_t range_words = (size_t)n_waves * mega_banks(), group_words = cap / 64 + 1;
     const bool tree = integ->scatter_rays != 1;
     const size_t stack_words = tree ? (size_t)integ->max_depth * 20 * ws.cap : 0;
-    rc = ensure_batch(ctx, (park_words + range_words + 2 * group_words + 2 * (size_t)n_waves + stack_words) * 4);
+    rc = ensure_batch(ctx, (range_words + 2 * group_words + 2 * (size_t)n_waves + stack_words) * 4);
     if (rc) return rc;
-    uint32_t* park = (uint32_t*)ctx->batch_buf;
+    uint32_t* buf = (uint32_t*)ctx->batch_buf;
     const MegaFrame F{make_region(*region), make_camera(*cam), (uint32_t)integ->antialiasing, integ->max_depth, integ->shadow_rays, S_shoot,
-                      (uint32_t)ctx->frame_step_min, out, park, park + park_words, park + park_words + range_words, park + park_words + range_words + group_words,
-                      integ->scatter_rays, (float*)(park + park_words + range_words + 2 * group_words + 2 * (size_t)n_waves),
-                      park + park_words + range_words + 2 * group_words};
+                      (uint32_t)ctx->frame_step_min, out, buf, buf + range_words, buf + range_words + group_words,
+                      integ->scatter_rays, (float*)(buf + range_words + 2 * group_words + 2 * (size_t)n_waves),
+                      buf + range_words + 2 * group_words};
     const uint32_t n_samples = (uint32_t)integ->antialiasing * (uint32_t)integ->antialiasing;
     // windows of samples: [0, 1) [1, w1) [w1, n); few samples, or rebalancing off: one window
     std::vector<uint32_t> ends;

@@ -183,7 +183,6 @@ struct MegaFrame {
     uint32_t n_shoot;
     uint32_t step_min;   // resumable pixels of a wave from which its integrator step runs without waiting for idle lanes (1..64)
     float* out;
-    uint32_t* park;      // 48 * 64 * mega_waves() words of scratch (lane state parked around the integrator step)
     uint32_t* units;     // mega_banks() words per wave (device): mega_assign
     uint32_t* owner;     // one word per unit of 64 slots (device): mega_assign
     uint32_t* group_cost;   // one word (a float) per unit (device)

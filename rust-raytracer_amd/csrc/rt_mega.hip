@@ -46,7 +46,6 @@ struct MegaParams {
     uint32_t n_shoot, step_min;
     uint32_t s_begin, s_end;   // the launch runs samples [s_begin, s_end) of every pixel
     float* out;
-    uint32_t* park;            // POOL_PARK_WORDS * 64 * n_waves words
     const uint32_t* units;     // MEGA_BANKS words per wave: the units the wave owns (MISS: none); unit u = slots [64 u, 64 u + 64)
     const uint32_t* owner;     // per unit: the wave that owns it
     uint32_t* group_cost;      // k_mega_group_cost: cost (a float) per unit
@@ -555,8 +554,6 @@ struct MegaIO {
     const lds_u32* unit_tab;   // the wave's MEGA_BANKS units (LDS); pixel p of the wave is slot 64 unit_tab[p / 64] + p % 64
     uint32_t step_min;
     uint64_t params;     // address of the kernel's argument block
-    uint32_t* park;      // lane state parked around pixel_step (rt_sched.h)
-    size_t park_stride;
     uint32_t* wave_scale;   // this wave's word of MegaParams::wave_scale
     uint32_t count;      // pixels of the wave
     uint32_t n_waves;
@@ -647,7 +644,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     }
     count = __builtin_amdgcn_readlane(wave_scan_add(count), 63);
     MegaIO<(MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD)> io{P.W.q_ray[0], P.W.set[0].a_ray, P.W.set[0].a_vidx, P.W.h_rec, P.W.set[0].vis, (unsigned long long*)P.W.stats, P.W.cap, P.W.any_cap, unit_tab, P.step_min,
-              (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(), P.park, (size_t)P.n_waves * 64u, P.wave_scale + wave_id, count, P.n_waves, P.scatter_rays != 1, pool};
+              (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(), P.wave_scale + wave_id, count, P.n_waves, P.scatter_rays != 1, pool};
     if (lane == 0u) P.wave_scale[wave_id] = (uint32_t)__builtin_amdgcn_s_memtime();
     if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, nullptr, 0u, 64u, pool, coop, ostack);
     else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, nullptr, 0u, 64u, pool, coop, ostack);
@@ -677,7 +674,7 @@ uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg) {
 static MegaParams mega_params(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n,
                               uint32_t s_begin, uint32_t s_end) {
     return MegaParams{S, W, F.R, F.cam, chunk_begin, chunk_n, F.aa, mega_waves(S, cfg), F.max_depth, F.shadow_rays, F.n_shoot, F.step_min, s_begin, s_end,
-                      F.out, F.park, F.units, F.owner, F.group_cost, F.scatter_rays, F.stack, F.wave_scale};
+                      F.out, F.units, F.owner, F.group_cost, F.scatter_rays, F.stack, F.wave_scale};
 }
 
 bool mega_supported(const DevScene& S, const LaunchCfg& cfg) {

@@ -458,13 +458,9 @@ static constexpr uint32_t POOL_PIXELS = 64u * POOL_PER_LANE, POOL_WORDS = POOL_P
 #define RTAMD_POOL_AHEAD 0
 #endif
 static constexpr uint32_t POOL_AHEAD = RTAMD_POOL_AHEAD;   // pixels up to this many samples ahead of the wave's last one are served with it
-static constexpr uint32_t POOL_PARK_WORDS = 48u;   // words of lane state parked around an integrator step
-#ifndef RTAMD_MEGA_PARK
-#define RTAMD_MEGA_PARK 0
-#endif
 static constexpr uint32_t POOL_TRIP_LIMIT = 1u << 24;   // scheduler steps of a wave per launch (a 256-spp chunk of an 8K frame takes about a million)
 // IO (MEGA) concept, besides decode / store_closest / store_any:
-//   lds_u32* pix; uint32_t step_min; uint32_t* park; size_t park_stride;   // park: POOL_PARK_WORDS rows of park_stride words (>= lanes of the launch)
+//   lds_u32* pix; uint32_t step_min;
 //   void ray_addr(uint32_t ref, const void* (&src)[8]) const;
 //   uint32_t step(uint32_t p, bool active) const;     // all 64 lanes call; returns the pixel's new word
 //   void finish(uint32_t lane, uint32_t n_closest, uint32_t n_any) const;
@@ -474,10 +470,10 @@ static constexpr uint32_t POOL_TRIP_LIMIT = 1u << 24;   // scheduler steps of a 
 #else
 #define POOL_DIAG(...)
 #endif
-template <class IO, class Start, class Before, class After>
+template <class IO, class Start>
 __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, uint32_t& st, uint32_t& fl, uint32_t& ridx, uint32_t& rtag, const Best& best,
-                                           const float wtmax, uint32_t& rot, uint32_t& n_closest, uint32_t& n_any, Start&& start, Before&& before_step,
-                                           After&& after_step, unsigned long long* dp /* diagnostic build: counters */) {
+                                           const float wtmax, uint32_t& rot, uint32_t& n_closest, uint32_t& n_any, Start&& start,
+                                           unsigned long long* dp /* diagnostic build: counters */) {
     volatile lds_u32* pix = io.pix;
     volatile lds_u32* list = io.pix + POOL_PIXELS;
     // (1) the rays that have finished count as returned from here on; their results are written further down, behind the loads of
@@ -547,11 +543,9 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
         const bool act = lane < n_step;
         const uint32_t p = act ? list[lane] : 0u;
         write_results();   // (the step reads them)
-        before_step();
         POOL_DIAG(const unsigned long long ps0 = __builtin_amdgcn_s_memtime();)
         const uint32_t nw = io.step(p, act);
         POOL_DIAG(dp[0] += 1; dp[1] += n_step; dp[2] += __builtin_amdgcn_s_memtime() - ps0;)
-        after_step();
         if (act) pix[p] = nw;
         asm volatile("" ::: "memory");
         scan();
@@ -983,34 +977,6 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
           }
     };
     uint32_t pool_trips = 0;
-    // (IO::MEGA) The integrator step is a call, and it needs the whole register file: whatever is live across it gets saved
-    // and restored by the compiler, which then makes room for that in the walks' loops as well.  The lane's state is instead
-    // written out by hand before the call and read back after it (row k of io.park: word k of every lane of the launch), so
-    // that nothing of it is live across the call.
-    constexpr bool MEGA_PARK = IO::MEGA && RTAMD_MEGA_PARK != 0;
-    auto lane_state = [&](auto save_c) {
-        if constexpr (IO::MEGA) {
-        constexpr bool SAVE = decltype(save_c)::value;
-        // (row address wave-uniform, the lane's place in it a 32-bit offset: one scalar base + one vector offset per access)
-        uint32_t* row = io.park;
-        const uint32_t at = wave_id * 64u + lane;
-        auto u = [&](uint32_t& v) {
-            if (SAVE) row[at] = v; else v = ((volatile uint32_t*)row)[at];
-            row += io.park_stride;
-        };
-        auto f = [&](float& v) {
-            if (SAVE) row[at] = __float_as_uint(v); else v = __uint_as_float(((volatile uint32_t*)row)[at]);
-            row += io.park_stride;
-        };
-        u(st); u(fl); u(ridx); u(rtag);
-        f(wpos.x); f(wpos.y); f(wpos.z); f(wdir.x); f(wdir.y); f(wdir.z); f(winv.x); f(winv.y); f(winv.z); f(wtmax);
-        u(best.obj); u(best.prim); f(best.t_local); f(best.u); f(best.v);
-        u(root_i); u(t_i); u(t_n); u(t_base); u(t_first); f(t_lim); u(o_cur); u(o_end); u(oi);
-        f(opos.x); f(opos.y); f(opos.z); f(odir.x); f(odir.y); f(odir.z); f(oinv.x); f(oinv.y); f(oinv.z); f(otmax); f(oscale);
-        u(n_i); u(n_n); u(node_off); u(tri_off); u(k_cur); u(k_end); u(oprim); f(ou); f(ov);
-        }
-    };
-    static_assert(POOL_PARK_WORDS >= 48u, "rows of the parking area");
     for (;;) {
         DIAG_TOP
         TL_TRIP
@@ -1305,7 +1271,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 root_i = run ? S.n_root : 0u; o_cur = run ? S.root_first : 0u; o_end = run ? S.root_first + S.n_root : 0u;
                 fl = any ? F_ANY : 0u;
                 st = ST_OBJ;
-            }, [&]() { if (MEGA_PARK) lane_state(std::true_type{}); }, [&]() { if (MEGA_PARK) lane_state(std::false_type{}); }, d_pool);
+            }, d_pool);
             }
         }
         if (!IO::MEGA && phase == ST_FETCH) {

@@ -1,6 +1,5 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 300 python -u tools/frame_kernel_check.py --cam 200x150 --aa 2 --scatter 2 --time "1080x960:2" --rebalance 0 --reps 3 2>&1 | grep "rebalance 0\|spp frame\|rror"
-timeout -k 10 300 python -u tools/frame_kernel_check.py --cam 200x150 --aa 2 --scatter 1 --time "1080x960:8" --rebalance 2 --reps 3 2>&1 | grep "rebalance 0\|spp frame\|rror"
-timeout -k 10 300 python -u tools/frame_kernel_check.py --scene spheres --cam 200x150 --aa 2 --scatter 2 --time "1080x960:2" --rebalance 0 --reps 3 2>&1 | grep "rebalance 0\|spp frame\|rror"
+timeout -k 10 300 python -u tools/frame_kernel_check.py --cam 200x150 --aa 2 --scatter 1 --time 1080x960:8 --rebalance 0 --reps 3 2>&1 | grep "spp frame\|False\|rror"
+timeout -k 10 300 python -u tools/frame_kernel_check.py --cam 200x150 --aa 2 --scatter 2 --time 1080x960:2 --rebalance 0 --reps 3 2>&1 | grep "spp frame\|False\|rror"
