@@ -454,6 +454,9 @@ static constexpr uint32_t PW_RDY_MASK = 0xFFu, PW_PEND_ONE = 0x100u, PW_PEND_MAS
 #endif
 static constexpr uint32_t POOL_PER_LANE = RTAMD_POOL_PER_LANE;   // pixels a lane looks after in the FETCH step's scans (at most 7: the pool's LDS)
 static constexpr uint32_t POOL_PIXELS = 64u * POOL_PER_LANE, POOL_WORDS = POOL_PIXELS + 64u;
+#ifndef RTAMD_SKIP_RUN
+#define RTAMD_SKIP_RUN 1
+#endif
 #ifndef RTAMD_POOL_AHEAD
 #define RTAMD_POOL_AHEAD 0
 #endif
@@ -1160,29 +1163,37 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                 DIAG_SUB_MARK
                 // (3) enter the next object
                 if (st == ST_OBJ && o_cur < o_end) {
-                    oi = o_cur++;
                     // the object's box in the space of the ray: most rays miss most objects, and this test needs neither
                     // the wrappers nor a reciprocal direction per object.  It only ever skips what the object's own first
                     // test would turn away (the comparisons are false for NaN, so nothing is skipped on one).
                     // Large scenes read the object's 32-byte instance record and take the rest from its class in LDS.
+                    // A run of objects that are skipped this way is passed in one step: a step is a trip of the whole wave
+                    // through vote and phase, the test of one more box a dozen instructions (headline frame +0.8 %).
                     const float tm_in = (fl & F_INTREE) ? walk_tmax() : wtmax;   // t_max the object is entered with
                     ObjHead ob;
-                    InstRec in = tab.inst(oi);
-                    const bool classed = Tab::has_inst && in.cls != CLS_NONE;
-                    if (classed) { ob = tab.cls_head(in.cls); ob.scale = in.scale; ob.inv_scale = in.inv_scale; }
-                    else ob = tab.object(oi);
-                    bool skip = false;
-                    if (ob.xf_kind & XF_BOX) {
-                        ObjBox ox;
-                        if (classed) { ox = tab.cls_box(in.cls); ox.mn = ox.mn + in.off; ox.mx = ox.mx + in.off; }
-                        else ox = tab.object_box(oi);
-                        // The slab roots carry a rounding error of a few ulps of the largest plane distance, which for a far
-                        // origin exceeds the fixed pad of the box: the interval is widened by that much before it is judged.
-                        const f3 pa = (ox.mn - wpos) * winv, pb = (ox.mx - wpos) * winv;
-                        const float bt0 = max2(min2(pa.x, pb.x), max2(min2(pa.y, pb.y), min2(pa.z, pb.z)));
-                        const float bt1 = min2(max2(pa.x, pb.x), min2(max2(pa.y, pb.y), max2(pa.z, pb.z)));
-                        const float err = 1e-6f * fmaxf(fabsf(bt0), fabsf(bt1)) + ox.slack;   // NaN or inf roots: nothing is skipped
-                        skip = (bt0 > bt1 + err) || (bt0 > tm_in * 1.00001f + err) || (bt1 < -err);
+                    InstRec in;
+                    bool classed, skip;
+                    for (;;) {
+                        oi = o_cur++;
+                        in = tab.inst(oi);
+                        classed = Tab::has_inst && in.cls != CLS_NONE;
+                        if (classed) { ob = tab.cls_head(in.cls); ob.scale = in.scale; ob.inv_scale = in.inv_scale; }
+                        else ob = tab.object(oi);
+                        skip = false;
+                        if (ob.xf_kind & XF_BOX) {
+                            ObjBox ox;
+                            if (classed) { ox = tab.cls_box(in.cls); ox.mn = ox.mn + in.off; ox.mx = ox.mx + in.off; }
+                            else ox = tab.object_box(oi);
+                            // The slab roots carry a rounding error of a few ulps of the largest plane distance, which for a far
+                            // origin exceeds the fixed pad of the box: the interval is widened by that much before it is judged.
+                            const f3 pa = (ox.mn - wpos) * winv, pb = (ox.mx - wpos) * winv;
+                            const float bt0 = max2(min2(pa.x, pb.x), max2(min2(pa.y, pb.y), min2(pa.z, pb.z)));
+                            const float bt1 = min2(max2(pa.x, pb.x), min2(max2(pa.y, pb.y), max2(pa.z, pb.z)));
+                            const float err = 1e-6f * fmaxf(fabsf(bt0), fabsf(bt1)) + ox.slack;   // NaN or inf roots: nothing is skipped
+                            skip = (bt0 > bt1 + err) || (bt0 > tm_in * 1.00001f + err) || (bt1 < -err);
+                        }
+                        // (scenes without meshes flag no object for the box test: there the loop only costs, 1.5 % of the sphere frame)
+                        if (!(RTAMD_SKIP_RUN != 0 && MESHLOC != MESH_NONE && skip && o_cur < o_end)) break;
                     }
                     if (!skip) {
                     ObjXf xf;   // read with the head: one round trip instead of two
