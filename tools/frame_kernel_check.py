@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--step-min", default="64")
     ap.add_argument("--rebalance", default="1", help="comma list of RTAMD_OPT_FRAME_REBALANCE values for the timed frame")
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--ranks", type=int, default=1, help="render the tiles rank 0 of this many would own (needs --tile)")
     ap.add_argument("--scatter", type=int, default=1)
     ap.add_argument("--scene", default="main", choices=["main", "spheres", "grid", "textured"])
     ap.add_argument("--reps", type=int, default=3)
@@ -55,7 +56,7 @@ def main():
     gpu = make((w, h)).upload(0)
     params = dict(max_depth=args.depth, shadow_rays=1, antialiasing=aa, scatter_rays=args.scatter)
     if args.tile:
-        params["region"] = rt.Scene.make_region(w, h, tile=(args.tile, args.tile))
+        params["region"] = rt.Scene.make_region(w, h, tile=(args.tile, args.tile), tile_first=0, tile_stride=args.ranks)
     ref = None
     for mode in [0] + [1] * len(args.step_min.split(",")):
         pass
