@@ -43,7 +43,7 @@ struct MegaParams {
     CameraDev cam;
     uint32_t chunk_begin, chunk_n, aa, n_waves;
     int32_t max_depth, shadow_rays;
-    uint32_t n_shoot, step_min;
+    uint32_t n_shoot, step_min, trip_limit;
     uint32_t s_begin, s_end;   // the launch runs samples [s_begin, s_end) of every pixel
     float* out;
     const uint32_t* units;     // MEGA_BANKS words per wave: the units the wave owns (MISS: none); unit u = slots [64 u, 64 u + 64)
@@ -552,7 +552,7 @@ struct MegaIO {
     unsigned long long* stats;
     uint32_t cap, any_cap;
     const lds_u32* unit_tab;   // the wave's MEGA_BANKS units (LDS); pixel p of the wave is slot 64 unit_tab[p / 64] + p % 64
-    uint32_t step_min;
+    uint32_t step_min, trip_limit;
     uint64_t params;     // address of the kernel's argument block
     uint32_t* wave_scale;   // this wave's word of MegaParams::wave_scale
     uint32_t count;      // pixels of the wave
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
         count += go ? 1u : 0u;
     }
     count = __builtin_amdgcn_readlane(wave_scan_add(count), 63);
-    MegaIO<(MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD)> io{P.W.q_ray[0], P.W.set[0].a_ray, P.W.set[0].a_vidx, P.W.h_rec, P.W.set[0].vis, (unsigned long long*)P.W.stats, P.W.cap, P.W.any_cap, unit_tab, P.step_min,
+    MegaIO<(MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD)> io{P.W.q_ray[0], P.W.set[0].a_ray, P.W.set[0].a_vidx, P.W.h_rec, P.W.set[0].vis, (unsigned long long*)P.W.stats, P.W.cap, P.W.any_cap, unit_tab, P.step_min, P.trip_limit,
               (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(), P.wave_scale + wave_id, count, P.n_waves, P.scatter_rays != 1, pool};
     if (lane == 0u) P.wave_scale[wave_id] = (uint32_t)__builtin_amdgcn_s_memtime();
     if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, nullptr, 0u, 64u, pool, coop, ostack);
@@ -673,7 +673,12 @@ uint32_t mega_waves(const DevScene& S, const LaunchCfg& cfg) {
 
 static MegaParams mega_params(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, const MegaFrame& F, uint32_t chunk_begin, uint32_t chunk_n,
                               uint32_t s_begin, uint32_t s_end) {
-    return MegaParams{S, W, F.R, F.cam, chunk_begin, chunk_n, F.aa, mega_waves(S, cfg), F.max_depth, F.shadow_rays, F.n_shoot, F.step_min, s_begin, s_end,
+    // A wave that does not come to an end gives up after this many scheduler steps.  The headline frame takes ~300 per sample (64 spp:
+    // 20 000 outside the mesh loops, which do not count); the limit leaves three orders of magnitude, for deep paths and large scenes.
+    const uint64_t per_sample = (uint64_t)1 << 18;
+    const uint64_t lim = per_sample * (s_end > s_begin ? s_end - s_begin : 1u) * (uint64_t)(F.scatter_rays > 1 ? 8 : 1);
+    const uint32_t trip_limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
+    return MegaParams{S, W, F.R, F.cam, chunk_begin, chunk_n, F.aa, mega_waves(S, cfg), F.max_depth, F.shadow_rays, F.n_shoot, F.step_min, trip_limit, s_begin, s_end,
                       F.out, F.units, F.owner, F.group_cost, F.scatter_rays, F.stack, F.wave_scale};
 }
 

@@ -461,9 +461,8 @@ static constexpr uint32_t POOL_PIXELS = 64u * POOL_PER_LANE, POOL_WORDS = POOL_P
 #define RTAMD_POOL_AHEAD 0
 #endif
 static constexpr uint32_t POOL_AHEAD = RTAMD_POOL_AHEAD;   // pixels up to this many samples ahead of the wave's last one are served with it
-static constexpr uint32_t POOL_TRIP_LIMIT = 1u << 24;   // scheduler steps of a wave per launch (a 256-spp chunk of an 8K frame takes about a million)
 // IO (MEGA) concept, besides decode / store_closest / store_any:
-//   lds_u32* pix; uint32_t step_min;
+//   lds_u32* pix; uint32_t step_min, trip_limit;   // trip_limit: scheduler steps after which a wave gives up
 //   void ray_addr(uint32_t ref, const void* (&src)[8]) const;
 //   uint32_t step(uint32_t p, bool active) const;     // all 64 lanes call; returns the pixel's new word
 //   void finish(uint32_t lane, uint32_t n_closest, uint32_t n_any) const;
@@ -984,7 +983,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         DIAG_TOP
         TL_TRIP
         if constexpr (IO::MEGA) {   // a wave that does not come to an end gives up (and says so) rather than hold the GPU
-            if (++pool_trips > POOL_TRIP_LIMIT) { io.fail(lane, 1u); break; }
+            if (++pool_trips > io.trip_limit) { io.fail(lane, 1u); break; }
         }
         // ---- vote: run the phase most lanes are waiting for ----
         const uint32_t c_tri = MESHLOC != MESH_NONE ? wave_count(st == ST_TRI) : 0u;
