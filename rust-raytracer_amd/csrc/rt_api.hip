@@ -1115,7 +1115,8 @@ static constexpr size_t FRAME_KERNEL_AUTO_SLOTS = 1310720;   // 1.25 Mi pixel sl
 int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd_integrator* integ, const rtamd_region* region, size_t total_slots,
                         uint32_t S_total, uint32_t S_shoot, float* out, rtamd_stats* stats) {
     const uint32_t n_waves = mega_waves(ctx->S, ctx->cfg);
-    const size_t cap = (size_t)n_waves * 256u;
+    // (a chunk leaves every wave one bank of its pool free on average, for the deal by cost)
+    const size_t cap = (size_t)n_waves * 64u * (mega_banks() - 1u);
     if (ctx->ws.empty()) ctx->ws.resize(1);
     rtamd_context::Workspace& ws = ctx->ws[0];
     int rc = ensure_wave(ctx, ws, cap, S_total);

@@ -611,10 +611,9 @@ struct MegaIO {
 template <int MESHLOC, int TABKIND, bool LEAN>
 __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD) void k_mega(MegaParams P) {
     const DevScene& S = P.S;
-    __shared__ uint32_t pool_mem[TRACE_BLOCK / 64][STAGE_WORDS];
+    __shared__ uint32_t pool_mem[TRACE_BLOCK / 64][POOL_WORDS > STAGE_WORDS ? POOL_WORDS : STAGE_WORDS];
     __shared__ unsigned long long coop_mem[TRACE_BLOCK / 64][MESHLOC == MESH_NONE ? 1 : COOP_WORDS / 2];   // (the triangle phase's)
     __shared__ unsigned long long ord_stack[TRACE_BLOCK / 64][sched_stack_depth(MESHLOC, TABKIND == TAB_LDS) ? 64 * sched_stack_depth(MESHLOC, TABKIND == TAB_LDS) : 1];
-    static_assert(POOL_WORDS <= STAGE_WORDS, "the pool takes the place of the ray staging buffer");
     lds_u32* pool = (lds_u32*)pool_mem[threadIdx.x >> 6];
     lds_u32* coop = (lds_u32*)coop_mem[threadIdx.x >> 6];
     lds_u32* ostack = (lds_u32*)ord_stack[threadIdx.x >> 6];
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     const uint32_t lane = lane_id();
     // the wave's units; every pixel of them that has samples left in this launch starts with its camera ray ready (k_mega_init, or
     // the launch before: pixel_step's leave)
-    __shared__ uint32_t unit_mem[TRACE_BLOCK / 64][8];
+    __shared__ uint32_t unit_mem[TRACE_BLOCK / 64][MEGA_BANKS < 8 ? 8 : 16];
     lds_u32* unit_tab = (lds_u32*)unit_mem[threadIdx.x >> 6];
     if (lane < MEGA_BANKS) ((volatile lds_u32*)unit_tab)[lane] = P.units[wave_id * MEGA_BANKS + lane];
     uint32_t count = 0;
@@ -740,7 +739,7 @@ void mega_assign(const float* cost, uint32_t chunk_n, uint32_t n_waves, uint32_t
         const uint32_t w = top.second;
         units[(size_t)w * MEGA_BANKS + held[w]++] = u;
         owner[u] = w;
-        if (held[w] < MEGA_BANKS) heap.push(Load(top.first + (double)cost[u], w));   // (a full wave leaves the heap: n_units <= n_waves * 4)
+        if (held[w] < MEGA_BANKS) heap.push(Load(top.first + (double)cost[u], w));   // (a full wave leaves the heap; the waves' banks hold more units than a chunk has)
     }
 }
 

@@ -452,7 +452,7 @@ static constexpr uint32_t PW_RDY_MASK = 0xFFu, PW_PEND_ONE = 0x100u, PW_PEND_MAS
 #ifndef RTAMD_POOL_PER_LANE
 #define RTAMD_POOL_PER_LANE 5
 #endif
-static constexpr uint32_t POOL_PER_LANE = RTAMD_POOL_PER_LANE;   // pixels a lane looks after in the FETCH step's scans (at most 7: the pool's LDS)
+static constexpr uint32_t POOL_PER_LANE = RTAMD_POOL_PER_LANE;   // pixels a lane looks after in the FETCH step's scans (at most 9: the counts' fields)
 static constexpr uint32_t POOL_PIXELS = 64u * POOL_PER_LANE, POOL_WORDS = POOL_PIXELS + 64u;
 #ifndef RTAMD_SKIP_RUN
 #define RTAMD_SKIP_RUN 1
@@ -513,18 +513,21 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
         for (int q = 0; q < PPL; q++) inv = max(inv, (w[q] & PW_ALIVE) ? 0x10000u - (w[q] >> PW_SAMPLE_SHIFT) : 0u);
         smin = 0x10000u - __builtin_amdgcn_readlane(wave_scan_max(inv), 63);
         own = 0; ownA = 0;
+        uint32_t alive_here = 0u;
 #pragma unroll
         for (int q = 0; q < PPL; q++) {
             const bool a = (w[q] & PW_ALIVE) && (w[q] >> PW_SAMPLE_SHIFT) <= smin + POOL_AHEAD;
             const uint32_t r = (uint32_t)__builtin_popcount(w[q] & PW_RDY_MASK), e = is_res(w[q]) ? (1u << 13) : 0u;
-            own += r + e + ((w[q] & PW_ALIVE) ? (1u << 22) : 0u);
+            own += r + e;
+            alive_here |= w[q] & PW_ALIVE;
             ownA += a ? r + e : 0u;
         }
         incl = wave_scan_add(own);
         inclA = wave_scan_add(ownA);
         const uint32_t tot = __builtin_amdgcn_readlane(incl, 63), totA = __builtin_amdgcn_readlane(inclA, 63);
-        t_rdy = tot & 0x1FFFu; t_res = (tot >> 13) & 0x1FFu; t_alive = tot >> 22;
-        tA_rdy = totA & 0x1FFFu; tA_res = (totA >> 13) & 0x1FFu;
+        // (counts of ready rays in bits 0-12, of resumable pixels above them: at most 8 x 64 x 9 and 64 x 9)
+        t_rdy = tot & 0x1FFFu; t_res = tot >> 13; t_alive = __ballot(alive_here != 0u) != 0ull ? 1u : 0u;
+        tA_rdy = totA & 0x1FFFu; tA_res = totA >> 13;
     };
     POOL_DIAG(unsigned long long pt = __builtin_amdgcn_s_memtime();)
     scan();
@@ -532,8 +535,8 @@ __device__ __forceinline__ void pool_fetch(const IO& io, const uint32_t lane, ui
     // (3) resumable pixels: run the integrator for them when there are enough to fill the wave, or when lanes would
     // otherwise go without a ray
     if (t_res > 0u && (t_res >= io.step_min || t_rdy < c_want)) {
-        uint32_t posA = ((inclA - ownA) >> 13) & 0x1FFu;
-        uint32_t posB = tA_res + (((incl - own) >> 13) & 0x1FFu) - posA;
+        uint32_t posA = (inclA - ownA) >> 13;
+        uint32_t posB = tA_res + ((incl - own) >> 13) - posA;
 #pragma unroll
         for (int q = 0; q < PPL; q++)
             if (is_res(w[q])) {

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--time", default="1080x960:8", help="WxH:aa of the timed frame ('' = none)")
     ap.add_argument("--step-min", default="64")
     ap.add_argument("--rebalance", default="1", help="comma list of RTAMD_OPT_FRAME_REBALANCE values for the timed frame")
+    ap.add_argument("--blocks", type=int, default=0, help="RTAMD_OPT_BLOCKS_PER_CU for the timed frames of the frame kernel")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ranks", type=int, default=1, help="render the tiles rank 0 of this many would own (needs --tile)")
     ap.add_argument("--scatter", type=int, default=1)
@@ -63,6 +64,7 @@ def main():
     runs = [(0, 64, 1)] + [(1, int(s), int(r)) for s in args.step_min.split(",") for r in args.rebalance.split(",")]
     for fk, smin, reb in runs:
         gpu.set_option(rt.OPT_FRAME_KERNEL, fk)
+        gpu.set_option(rt.OPT_BLOCKS_PER_CU, args.blocks if (fk and args.blocks) else 2)
         gpu.set_option(rt.OPT_FRAME_STEP_MIN, smin)
         gpu.set_option(rt.OPT_FRAME_REBALANCE, reb)
         img, st = gpu.render(**params)
