@@ -129,7 +129,8 @@ void* orc_scene_main(const char* ply_path, const uint8_t* sky_rgb, int sky_w, in
 
 // Synthetic: n spheres (each its own Object, alternating Lambertian / Metal) in one AABBTree<Object>
 // (hit_cost 1.0) + a floor cuboid.  Centres uniform in [-12,12]^2 x [0.3,4.0], radii in [0.08,0.25].
-void* orc_scene_spheres(int n, uint64_t seed, const uint8_t* sky_rgb, int sky_w, int sky_h, int cam_w, int cam_h) {
+// `scale` multiplies every length of the scene in f32 after it is drawn (1.0: every value as drawn).
+void* orc_scene_spheres_scaled(int n, uint64_t seed, float scale, const uint8_t* sky_rgb, int sky_w, int sky_h, int cam_w, int cam_h) {
     auto* s = new OrcScene();
     SplitMix64 g{seed};
     std::vector<Object> objs;
@@ -139,22 +140,25 @@ void* orc_scene_spheres(int n, uint64_t seed, const uint8_t* sky_rgb, int sky_w,
         float cy = -12.0f + 24.0f * g.uniform();
         float cz = 0.3f + 3.7f * g.uniform();
         float r = 0.08f + 0.17f * g.uniform();
-        objs.emplace_back(make_sphere(V3(cx, cy, cz), r), (i % 2 == 0) ? mat_lambert(V3(1.f, 1.f, 1.f)) : mat_metal());
+        objs.emplace_back(make_sphere(V3(cx * scale, cy * scale, cz * scale), r * scale), (i % 2 == 0) ? mat_lambert(V3(1.f, 1.f, 1.f)) : mat_metal());
     }
     s->object_tree = std::make_shared<AABBTree<Object>>(std::move(objs), 1.0f);
     std::vector<std::shared_ptr<Object>> root_objs;
-    root_objs.push_back(std::make_shared<Object>(std::make_shared<Cuboid>(V3(-15.0f, -15.0f, 0.0f), V3(15.0f, 15.0f, -1.0f)),
+    root_objs.push_back(std::make_shared<Object>(std::make_shared<Cuboid>(V3(-15.0f * scale, -15.0f * scale, 0.0f), V3(15.0f * scale, 15.0f * scale, -1.0f * scale)),
                                                  mat_glossy(1e3f, 0.3f, V3(1.f, 1.f, 1.f))));
     auto list = std::make_shared<GeometryList>();
     list->items.push_back(s->object_tree);
     for (auto& o : root_objs) list->items.push_back(o);
     finalize_object_ids(s, root_objs);
-    s->cam_pos = V3(-18.0f, -18.0f, 9.0f); s->cam_focus = V3(0.0f, 0.0f, 1.0f); s->cam_up = -V3(0.f, 0.f, 1.f);
+    s->cam_pos = V3(-18.0f * scale, -18.0f * scale, 9.0f * scale); s->cam_focus = V3(0.0f, 0.0f, 1.0f * scale); s->cam_up = -V3(0.f, 0.f, 1.f);
     s->make_camera((size_t)cam_w, (size_t)cam_h);
     s->scene.root = list;
     s->scene.skybox = make_sky(sky_rgb, sky_w, sky_h);
     s->scene.lights = main_lights();
     return s;
+}
+void* orc_scene_spheres(int n, uint64_t seed, const uint8_t* sky_rgb, int sky_w, int sky_h, int cam_w, int cam_h) {
+    return orc_scene_spheres_scaled(n, seed, 1.0f, sky_rgb, sky_w, sky_h, cam_w, cam_h);
 }
 
 // Synthetic: every texture and the materials main.rs leaves out, in a plain GeometryList (same construction as the

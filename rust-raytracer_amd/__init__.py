@@ -130,6 +130,8 @@ def host_lib():
         _host.rth_scene_main.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_spheres.restype = C.c_void_p
         _host.rth_scene_spheres.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _host.rth_scene_spheres_scaled.restype = C.c_void_p
+        _host.rth_scene_spheres_scaled.argtypes = [C.c_int, C.c_uint64, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_terrain.restype = C.c_void_p
         _host.rth_scene_terrain.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _host.rth_scene_textured.restype = C.c_void_p
@@ -197,8 +199,11 @@ class Scene:
         return cls(host_lib().rth_scene_main(ply.encode(), p, w, h, cam[0], cam[1]), sky)
 
     @classmethod
-    def spheres(cls, n=10000, seed=1, sky=None, cam=(1080, 960)):
+    def spheres(cls, n=10000, seed=1, sky=None, cam=(1080, 960), scale=None):
+        """n spheres in one object tree over a floor; scale: every length of the scene multiplied by it (f32)."""
         sky, p, w, h = cls._sky_args(sky)
+        if scale is not None:
+            return cls(host_lib().rth_scene_spheres_scaled(n, seed, scale, p, w, h, cam[0], cam[1]), sky)
         return cls(host_lib().rth_scene_spheres(n, seed, p, w, h, cam[0], cam[1]), sky)
 
     @classmethod

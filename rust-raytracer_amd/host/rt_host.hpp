@@ -347,7 +347,7 @@ std::shared_ptr<Mesh> load_ply_as_mesh(const std::string& path);
 // src/main.rs:22-83 with caller-supplied asset locations.
 Scene scene_main(const std::string& ply_path, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
 // Synthetic scenes of the larger benchmark configurations (generator: splitmix64, see rt_scenes.cpp).
-Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h);
+Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, float scale = 1.0f);
 // flat 1: every instance is a mesh of its own with world-space vertices (no ray transform); flat 2: the instances of each
 // of the three materials merged into one world-space mesh (its tree built on `builder` when given); see rt_scenes.cpp
 Scene scene_grid(const std::string& ply_path, int nx, int ny, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, int flat = 0, Device* builder = nullptr);

@@ -42,6 +42,10 @@ void* rth_scene_main(const char* ply, const uint8_t* sky, int sw, int sh, int ca
 void* rth_scene_spheres(int n, uint64_t seed, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_spheres(n, seed, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
 }
+// The same scene with every length multiplied by `scale` (a tree of tiny objects far from the rays that meet it).
+void* rth_scene_spheres_scaled(int n, uint64_t seed, float scale, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
+    return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_spheres(n, seed, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h, scale); return h; });
+}
 void* rth_scene_grid(const char* ply, int nx, int ny, const uint8_t* sky, int sw, int sh, int cam_w, int cam_h) {
     return guarded([&]() -> void* { auto* h = new Handle(); h->scene = scene_grid(ply, nx, ny, sky_from(sky, sw, sh), (size_t)cam_w, (size_t)cam_h); return h; });
 }

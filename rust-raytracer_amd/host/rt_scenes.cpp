@@ -59,8 +59,9 @@ struct SplitMix64 {
 
 // n spheres, each its own Object (even index: white Lambertian, odd: Metal), in one AABBTree<Object>
 // with hit_cost 1.0, above a glossy floor cuboid.  Centres uniform in [-12,12]^2 x [0.3,4.0], radii
-// uniform in [0.08,0.25]; per sphere the generator is drawn in the order cx, cy, cz, r.
-Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h) {
+// uniform in [0.08,0.25]; per sphere the generator is drawn in the order cx, cy, cz, r.  `scale` multiplies every length of
+// the scene (centres, radii, floor, camera position and focus) in f32 after it is drawn: 1.0 leaves every value as it is.
+Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, size_t cam_w, size_t cam_h, float scale) {
     SplitMix64 g{seed};
     std::vector<Object> objs;
     objs.reserve((size_t)n);
@@ -69,13 +70,14 @@ Scene scene_spheres(int n, uint64_t seed, std::shared_ptr<const Image> skybox, s
         float cy = -12.0f + 24.0f * g.uniform();
         float cz = 0.3f + 3.7f * g.uniform();
         float r = 0.08f + 0.17f * g.uniform();
-        objs.push_back(Object::with_material(Sphere(Vec3D(cx, cy, cz), r), (i % 2 == 0) ? Lambartian(COLOR_WHITE) : Metal()));
+        objs.push_back(Object::with_material(Sphere(Vec3D(cx * scale, cy * scale, cz * scale), r * scale), (i % 2 == 0) ? Lambartian(COLOR_WHITE) : Metal()));
     }
     Scene scene;
     scene.root.push(ObjectTree::make(std::move(objs), 1.0f));
-    scene.root.push(Object::with_material(Cuboid::make(vec3d(-15.0f, -15.0f, 0.0f), vec3d(15.0f, 15.0f, -1.0f)), Glossy(1e3f, 0.3f, COLOR_WHITE)));
+    scene.root.push(Object::with_material(Cuboid::make(vec3d(-15.0f * scale, -15.0f * scale, 0.0f), vec3d(15.0f * scale, 15.0f * scale, -1.0f * scale)),
+                                          Glossy(1e3f, 0.3f, COLOR_WHITE)));
     Camera cam(cam_w, cam_h);
-    cam.position(Vec3D(-18.0f, -18.0f, 9.0f)).look_at(Vec3D(0.0f, 0.0f, 1.0f), -Vec3D::z_axis());
+    cam.position(Vec3D(-18.0f * scale, -18.0f * scale, 9.0f * scale)).look_at(Vec3D(0.0f, 0.0f, 1.0f * scale), -Vec3D::z_axis());
     scene.camera = cam;
     scene.skybox = skybox;
     scene.lights = main_lights();

@@ -42,6 +42,8 @@ def lib():
         _lib.orc_scene_main.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_spheres.restype = C.c_void_p
         _lib.orc_scene_spheres.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.orc_scene_spheres_scaled.restype = C.c_void_p
+        _lib.orc_scene_spheres_scaled.argtypes = [C.c_int, C.c_uint64, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_textured.restype = C.c_void_p
         _lib.orc_scene_textured.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.orc_scene_terrain.restype = C.c_void_p
@@ -111,9 +113,12 @@ class OracleScene:
         return cls(hnd, sky)
 
     @classmethod
-    def spheres(cls, n=10000, seed=1, sky=None, cam=(1080, 960)):
+    def spheres(cls, n=10000, seed=1, sky=None, cam=(1080, 960), scale=None):
         sky = procedural_sky() if sky is None else np.ascontiguousarray(sky, dtype=np.uint8)
-        hnd = lib().orc_scene_spheres(n, seed, sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
+        if scale is not None:
+            hnd = lib().orc_scene_spheres_scaled(n, seed, scale, sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
+        else:
+            hnd = lib().orc_scene_spheres(n, seed, sky.ctypes.data, sky.shape[1], sky.shape[0], cam[0], cam[1])
         return cls(hnd, sky)
 
     @classmethod

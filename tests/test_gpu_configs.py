@@ -145,6 +145,57 @@ def test_spheres_10000(rt, ol, sky):
     compare(img, ref_img)
 
 
+def aimed_rays(n, seed, dist, scale):
+    """Rays from `dist` away (all around, above the floor) aimed into the box of the sphere scene scaled by `scale`."""
+    rng = np.random.default_rng(seed)
+    a, el = rng.uniform(0.0, 2.0 * np.pi, n), rng.uniform(0.05, 1.2, n)
+    o = dist * np.stack([np.cos(a) * np.cos(el), np.sin(a) * np.cos(el), np.sin(el)])
+    target = np.stack([rng.uniform(-12, 12, n), rng.uniform(-12, 12, n), rng.uniform(0, 4, n)]) * scale
+    rays = np.zeros((7, n), np.float32)
+    rays[0:3] = o
+    d = target - rays[0:3].astype(np.float64)
+    rays[3:6] = (d / np.linalg.norm(d, axis=0)).astype(np.float32)
+    dn = np.sqrt((rays[3:6].astype(np.float64) ** 2).sum(axis=0))         # unit directions in f32 (sphere.rs:22-33 assumes them)
+    rays[3:6] = (rays[3:6] / dn).astype(np.float32)
+    rays[6] = 1e12
+    return rays
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1e-5])
+def test_tiny_sphere_tree_seen_from_far_walk_in_passes(rt, ol, sky, scale):
+    """A tree of 2000 spheres (more than 257 nodes: the walk in passes applies) scaled to 1e-4 / 1e-5 and met by rays from
+    0.01 to 2000 units away: the spacing of the objects is near or below the resolution of the ray parameter at the tree's
+    entry point, so a pass limit may have no room to grow.  Such a walk must be dropped to the single walk, not repeated
+    for ever, and every ray must get the single walk's answer (and the oracle's)."""
+    cam = (64, 48)
+    host = rt.Scene.spheres(n=2000, seed=3, sky=sky, cam=cam, scale=scale)
+    assert host.tree(1)[0].shape[0] >= 257
+    gpu = host.upload(0)
+    cpu = ol.OracleScene.spheres(n=2000, seed=3, sky=sky, cam=cam, scale=scale)
+    rays = np.ascontiguousarray(np.concatenate([aimed_rays(8000, 90 + k, dist, scale) for k, dist in
+                                                enumerate((0.01, 0.3, 1.0, 30.0, 300.0, 1000.0, 1500.0, 2000.0, 2500.0))], axis=1))
+    ref = cpu.trace_closest(rays)
+    a = gpu.trace_closest(rays)
+    hits = check_closest(rt, a, ref, exact_uv=False)
+    assert hits > 0.3 * rays.shape[1]
+    any_rays = rays.copy()
+    any_rays[6] = np.random.default_rng(7).choice(np.array([0.5, 1000.0, 1e12], np.float32), rays.shape[1])
+    occ = gpu.trace_any(any_rays)
+    assert np.array_equal(occ, cpu.trace_any(any_rays)[0])
+    try:
+        gpu.set_option(rt.OPT_TREE_DEEPENING, 2)                           # the walk in passes, in the batch entry points too
+        b = gpu.trace_closest(rays)
+        occ_b = gpu.trace_any(any_rays)
+    finally:
+        gpu.set_option(rt.OPT_TREE_DEEPENING, 1)
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert np.array_equal(occ, occ_b)
+    img, _ = gpu.render(max_depth=3, shadow_rays=1, antialiasing=1)       # the render entry points walk in passes by default
+    ref_img, _, _ = cpu.render(max_depth=3, shadow_rays=1, antialiasing=1)
+    compare(img, ref_img)
+
+
 def test_real_skybox_render(rt, ol):
     """assets/skybox.jpg (6900 x 3450, decoded by PIL on both sides) through the miss shader: the first + y * w + x texel path."""
     real = ol.load_skybox()
