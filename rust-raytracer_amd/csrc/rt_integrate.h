@@ -232,16 +232,39 @@ __device__ __forceinline__ bool light_shoots(const DevLight& l) {
     return true;
 }
 
+// Order of the pixel slots inside a tile (RegionDev::squares, chosen by the host per frame): squares of 8 x 8 pixels, row of
+// squares by row of squares (the 64 consecutive slots of a wave are then a square of the image and not a line of it: the
+// texels, hit records and triangles its lanes read lie closer together), or the rows of the tile.
+__device__ __forceinline__ void tile_xy(const RegionDev& R, uint32_t r, uint32_t& tx, uint32_t& ty) {
+    if (R.squares != 0u) {
+        const uint32_t b = r >> 6, in = r & 63u, per_row = R.tile_w >> 3;
+        const uint32_t by = b / per_row, bx = b - by * per_row;
+        tx = bx * 8u + (in & 7u); ty = by * 8u + (in >> 3);
+    } else {
+        ty = r / R.tile_w; tx = r - ty * R.tile_w;
+    }
+}
+
 // Pixel slot -> pixel coordinates of the owned tile set (see rtamd_region).
 __device__ __forceinline__ bool slot_pixel(const RegionDev& R, uint32_t slot, uint32_t& cx, uint32_t& cy) {
     uint32_t per_tile = R.tile_w * R.tile_h;
     uint32_t q = slot / per_tile, r = slot - q * per_tile;
-    uint32_t ty = r / R.tile_w, tx = r - ty * R.tile_w;
+    uint32_t tx, ty;
+    tile_xy(R, r, tx, ty);
     uint32_t tile = R.tile_first + q * R.tile_stride;
     uint32_t tyi = tile / R.tiles_x, txi = tile - tyi * R.tiles_x;
     uint32_t px = txi * R.tile_w + tx, py = tyi * R.tile_h + ty;
     cx = R.x0 + px; cy = R.y0 + py;
     return px < R.w && py < R.h && tile < R.n_tiles;
+}
+
+// Pixel slot -> index of its pixel in the output image (owned tiles one after the other, each row-major: rtamd_region).
+__device__ __forceinline__ size_t slot_out(const RegionDev& R, uint32_t slot) {
+    uint32_t per_tile = R.tile_w * R.tile_h;
+    uint32_t q = slot / per_tile, r = slot - q * per_tile;
+    uint32_t tx, ty;
+    tile_xy(R, r, tx, ty);
+    return (size_t)q * per_tile + (size_t)ty * R.tile_w + tx;
 }
 
 // Direction of the camera ray through sample (si, sj) of pixel (cx, cy): integrator.rs:41-42, scene.rs:84-90.

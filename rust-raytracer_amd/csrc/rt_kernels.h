@@ -43,6 +43,7 @@ struct RegionDev {
     uint32_t x0, y0, w, h;
     uint32_t tile_w, tile_h, tile_first, tile_stride;
     uint32_t tiles_x, n_tiles;
+    uint32_t squares;   // order of the slots inside a tile: 1 = squares of 8 x 8 pixels (both sides of the tile multiples of 8), 0 = rows
 };
 
 struct ShadeSet {

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_finalize(WaveBufs W, RegionDev R, uint3
     if (i >= chunk_n) return;
     uint32_t cx, cy;
     bool valid = slot_pixel(R, chunk_begin + i, cx, cy);
-    size_t o = 3 * (size_t)(chunk_begin + i);
+    size_t o = 3 * slot_out(R, chunk_begin + i);
     if (valid) {
         // the samples are added in generation order (integrator.rs:50-53): the sum, then the last two passes
 #pragma unroll
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void k_pixel_depth_first(DevScene S, RegionDev
             }
             total = total / (float)(aa * aa);
         }
-        const size_t o = 3 * (size_t)(chunk_begin + i);
+        const size_t o = 3 * slot_out(R, chunk_begin + i);
         out[o] = total.x; out[o + 1] = total.y; out[o + 2] = total.z;
     }
     // ray counts: one pair of atomics per wave
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(DF_BLOCK) void k_df_begin(WaveBufs W, DfParams X, u
         o[q] = X.cam.pos.x; o[q + cap] = X.cam.pos.y; o[q + 2 * cap] = X.cam.pos.z;
         o[q + 3 * cap] = dir.x; o[q + 4 * cap] = dir.y; o[q + 5 * cap] = dir.z;
     } else if (i < chunk_n) {
-        const size_t o = 3 * (size_t)(X.chunk_begin + i);
+        const size_t o = 3 * slot_out(X.R, X.chunk_begin + i);
         X.out[o] = 0.0f; X.out[o + 1] = 0.0f; X.out[o + 2] = 0.0f;
     }
 }
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(DF_BLOCK) void k_df_step(DevScene S, WaveBufs W, Df
                             want_ray = true; new_state = DF_ENTER;
                         } else {
                             total = total / (float)(X.aa * X.aa);
-                            const size_t o = 3 * (size_t)(X.chunk_begin + slot);
+                            const size_t o = 3 * slot_out(X.R, X.chunk_begin + slot);
                             X.out[o] = total.x; X.out[o + 1] = total.y; X.out[o + 2] = total.z;
                             done = true;
                         }

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_mega_init(MegaParams P) {
     W.p_slot[j] = 0u;
     if (!slot_pixel(P.R, P.chunk_begin + j, cx, cy)) {
         W.q_slot[0][j] = 0u;
-        float* o = P.out + 3 * (size_t)(P.chunk_begin + j);
+        float* o = P.out + 3 * slot_out(P.R, P.chunk_begin + j);
         o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
         return;
     }
@@ -182,7 +182,7 @@ __device__ __attribute__((noinline)) uint32_t pixel_step(const uint64_t params, 
         const uint32_t aa = P->aa, n_samples = aa * aa;
         if (sample_done + 1u >= n_samples) {
             const float n = (float)n_samples;
-            float* o = P->out + 3 * (size_t)(P->chunk_begin + j);
+            float* o = P->out + 3 * slot_out(P->R, P->chunk_begin + j);
             o[0] = total.x / n; o[1] = total.y / n; o[2] = total.z / n;
             return 0u;
         }
@@ -508,7 +508,7 @@ __device__ __attribute__((noinline)) uint32_t pixel_step_tree(const uint64_t par
                     leaving = pass >= P->s_end;   // (that ray is the next launch's)
                 } else {
                     total = total / (float)(aa * aa);
-                    float* o = P->out + 3 * (size_t)(P->chunk_begin + slot);
+                    float* o = P->out + 3 * slot_out(P->R, P->chunk_begin + slot);
                     o[0] = total.x; o[1] = total.y; o[2] = total.z;
                     done = true;
                 }
