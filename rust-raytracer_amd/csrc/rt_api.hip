@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "rt_kernels.h"
@@ -1282,6 +1283,8 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     RegionDev R = make_region(*region);
     const CameraDev C = make_camera(*cam);
 
+    static const bool host_timing = std::getenv("RTAMD_HOST_TIMING") != nullptr;
+    const auto ht0 = std::chrono::steady_clock::now();
     hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
     HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
     for (size_t w = 0; w < n_ws; w++) {
@@ -1398,17 +1401,25 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
             }
         }
     }
+    const auto ht1 = std::chrono::steady_clock::now();
     std::vector<uint64_t> hstats(4 * n_ws, 0);
     for (size_t w = 0; w < n_ws; w++) {
         HIP_TRY(ctx, hipMemcpyAsync(&hstats[4 * w], ctx->ws[w].W.stats, 32, hipMemcpyDeviceToHost, ctx->ws[w].stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ws[w].done, ctx->ws[w].stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws[w].done, 0));
     }
+    const auto ht2 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const auto ht3 = std::chrono::steady_clock::now();
     for (size_t w = 1; w < n_ws; w++) { hstats[0] += hstats[4 * w]; hstats[1] += hstats[4 * w + 1]; }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
+    if (host_timing) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "rtamd host timing: submit %.0f us, stats copy %.0f us, record + sync %.0f us, total %.0f us, device %.0f us\n", us(ht0, ht1), us(ht1, ht2),
+                     us(ht2, ht3), us(ht0, ht3), ms * 1e3);
+    }
     ctx->event_pool.push_back(ev0);
     ctx->event_pool.push_back(ev1);
     if (stats) {

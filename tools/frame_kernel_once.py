@@ -12,5 +12,6 @@ rt = entry.load_package()
 gpu = rt.Scene.main(sky=rt.load_skybox(max_width=512), cam=(1080, 960)).upload(0)
 gpu.set_option(rt.OPT_FRAME_KERNEL, int(sys.argv[1]))
 aa = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-img, st = gpu.render(max_depth=5, shadow_rays=1, antialiasing=aa)
-print(st)
+for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
+    img, st = gpu.render(max_depth=5, shadow_rays=1, antialiasing=aa)
+    print(st)

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-for t in 64 32 16 8; do
+for t in 64 40 24 120 8; do
 sed "s/^TILE = 64/TILE = $t/" bench.py > /tmp/bench_t.py
 cp /tmp/bench_t.py bench_tile_probe.py
 echo -n "tile $t: "
