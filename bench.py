@@ -56,7 +56,7 @@ WORKLOADS = {
                                                                    "triangles each (trees built on the GPU) + floor cuboid in a plain list + skybox.jpg"),
 }
 DEFAULT_WORKLOAD = "bunny_1080x960_64spp_depth5"
-TILE = 64
+TILE = 40                        # divides every workload's frame (1080x960: 27 x 24 tiles, 81 per rank of 8; no partial tiles: 64-pixel tiles leave 0.7 % of the pixel slots empty)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4
