@@ -1139,7 +1139,8 @@ int render_frame_kernel(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     rc = ensure_batch(ctx, (range_words + 2 * group_words + 2 * (size_t)n_waves + stack_words) * 4);
     if (rc) return rc;
     uint32_t* buf = (uint32_t*)ctx->batch_buf;
-    const MegaFrame F{make_region(*region, false), make_camera(*cam), (uint32_t)integ->antialiasing, integ->max_depth, integ->shadow_rays, S_shoot,
+    static const bool frame_squares = std::getenv("RTAMD_FRAME_SQUARES") != nullptr;   // (experiments: the frame kernel on 8 x 8 squares)
+    const MegaFrame F{make_region(*region, frame_squares), make_camera(*cam), (uint32_t)integ->antialiasing, integ->max_depth, integ->shadow_rays, S_shoot,
                       (uint32_t)ctx->frame_step_min, out, buf, buf + range_words, buf + range_words + group_words,
                       integ->scatter_rays, (float*)(buf + range_words + 2 * group_words + 2 * (size_t)n_waves),
                       buf + range_words + 2 * group_words};
