@@ -1289,6 +1289,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
         }
         if (!IO::MEGA && phase == ST_FETCH) {
             DIAG_STEP(ST_FETCH, c_fetch)
+            DIAG_SUB_BEGIN
             const bool want = st == ST_FETCH;
             // hand out staged rays to the lanes that want one
             const unsigned long long need = __ballot(want);
@@ -1298,9 +1299,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
             const bool got = want && rank < take;
             uint32_t raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (take > 0) {
-                { DIAG_SUB_BEGIN
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the batch was requested in an earlier FETCH step
-                DIAG_SUB_END(0) }
                 const uint32_t src = (sg_pos + rank) & 63u;
 #pragma unroll
                 for (int c = 0; c < 8; c++) raw[c] = stage[c * 64 + src];
@@ -1309,6 +1308,7 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     for (int c = 0; c < 8; c++) { const uint32_t z = ((volatile lds_u32*)stage)[c * 64 + src]; asm volatile("" ::"v"(z)); }
                 }
             }
+            DIAG_SUB_END(0)
             { DIAG_SUB_BEGIN
             if (want && (fl & F_HAVE)) {
                 if (fl & F_ANY) io.store_any(ridx, rtag, (fl & F_OCC) != 0u);
@@ -1365,12 +1365,13 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
                     chunk_next += sg_cnt;
                     const void* src[8];
                     io.stage_addr(sg_base + (lane < sg_cnt ? lane : sg_cnt - 1u), src);
+                    DIAG_SUB_END(7)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of the old batch have returned
 #pragma unroll
                     for (int c = 0; c < 8; c++) stage_row(src[c], stage_lds + (uint32_t)c * 256u);
                 }
             }
-            DIAG_SUB_END(7) }
+            }
             if (st == ST_FETCH && exhausted && sg_cnt == 0) st = ST_DONE;
         }
         DIAG_END(phase)
