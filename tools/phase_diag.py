@@ -68,7 +68,7 @@ def main():
                 print(f"  {name:6s} cycles {100 * cyc / total:5.1f}%  steps {int(steps):>12d}  lanes/step {lanes / steps:5.1f}  "
                       f"cycles/step {cyc / steps:7.1f}  lane-steps/ray {lanes / rays:6.2f}")
         sub = np.array(list(buf), dtype=np.float64)[15:31].reshape(8, 2)
-        for name, (cyc, cnt) in zip(("fetch: wait for staged batch", "fetch: queue-head atomic", "fetch: result stores", "obj: fold + next object", "obj: record + wrappers", "obj: mesh entry + root box", "fetch: decode + ray setup", "fetch: next-batch request"), sub):
+        for name, (cyc, cnt) in zip(("fetch: hand-out (wait + reads of the staged batch)", "fetch: queue-head atomic", "fetch: result stores", "obj: fold + next object", "obj: record + wrappers", "obj: mesh entry + root box", "fetch: decode + ray setup", "fetch: next batch (deal, claim, addresses; per request)"), sub):
             if cnt:
                 print(f"  {name:30s} {100 * cyc / total:5.1f}% of cycles  n {int(cnt):>10d}  cycles each {cyc / cnt:8.1f}")
         if args.frame:
