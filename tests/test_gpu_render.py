@@ -105,17 +105,18 @@ def test_depth_first_rounds_equal_the_one_lane_kernel(rt, pair, params):
 
 
 def test_tiles_equal_full_frame_bitwise(rt, pair):
-    """Any tile decomposition yields identical pixels: the seed depends only on (cx, cy)."""
+    """Any tile decomposition yields identical pixels: the seed depends only on (cx, cy).  Tiles whose sides are multiples of
+    8 are walked in squares of 8 x 8 pixels, the others row by row: the image must not show which."""
     gpu, _, cam = pair
     full, _ = gpu.render(max_depth=4, shadow_rays=1, antialiasing=2)
     W, H = cam
-    for world in (2, 3):
+    for world, tile in ((2, (64, 48)), (3, (64, 48)), (2, (36, 20)), (3, (40, 40)), (2, (8, 8)), (1, (W, H - 1))):
         image = np.zeros((H, W, 3), np.float32)
         for rank in range(world):
-            region = rt.Scene.make_region(W, H, tile=(64, 48), tile_first=rank, tile_stride=world)
+            region = rt.Scene.make_region(W, H, tile=tile, tile_first=rank, tile_stride=world)
             tiles, _ = gpu.render(max_depth=4, shadow_rays=1, antialiasing=2, region=region)
             rt.assemble_tiles(tiles, region, rank, world, image)
-        assert np.array_equal(image.view(np.uint32), full.view(np.uint32))
+        assert np.array_equal(image.view(np.uint32), full.view(np.uint32)), (world, tile)
 
 
 def test_sub_rectangle_and_chunking(rt, pair):
