@@ -232,16 +232,29 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the render path)")
     # RTAMD_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
     # the gather goes through host memory); the driver's runs use the default, RCCL with one GPU per rank.
-    backend = os.environ.get("RTAMD_BENCH_BACKEND", "nccl")
+    # (also chosen by itself when the launcher starts more local ranks than the box has GPUs)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    backend = os.environ.get("RTAMD_BENCH_BACKEND") or ("nccl" if torch.cuda.device_count() >= local_world else "gloo")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # what the communication libraries print while they connect (gloo: "[Gloo] Rank ... is connected ...") goes to
+        # stderr: stdout carries the one JSON line
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     rt = entry.load_package()
     from rust_raytracer_amd import dist_tiles
