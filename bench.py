@@ -12,12 +12,14 @@ Metric: Mrays/s = (closest-hit + any-hit rays traced) / wall time, whole job.
 Other workloads: the 4K primary-ray batch (configs[1]), 10 000 spheres in an object tree at 3840x2160 / 64 spp
 (configs[3]) and the 230 x 230 instanced-bunny grid (50.1 M triangles) at 7680x4320 / 256 spp (configs[4]).
 
-N > 1: the SAME frame is cut into 64x64 tiles that are dealt round-robin to the ranks (one rank per GPU, scene
-replicated), every rank renders its tiles and the framebuffer is gathered to rank 0 with one RCCL gather inside the
-timed region: total work is fixed, i.e. strong scaling.  `--weak` grows the frame with N instead (N x the pixels at
-the same camera and aspect ratio) and says so in `config`.  `python bench.py --gpus N` from a plain shell starts its
-own N ranks (torch.distributed.run, 127.0.0.1) before anything touches the GPU; under torch.distributed.run it is one
-of the ranks.  On a box with fewer GPUs than ranks the ranks share devices and gather through gloo (a rehearsal).
+N > 1: image tiles are the units that shard (40x40 pixels, dealt round-robin to the ranks, one rank per GPU, scene
+replicated; no data-path collective besides the framebuffer gather to rank 0, one RCCL gather inside the timed region).
+Default: weak scaling -- the frame grows with N (N x the pixels of the workload's frame at the same camera and aspect
+ratio, sides rounded to whole tiles), so every rank renders as many pixels of the same picture as the single GPU does.
+`--strong` cuts the workload's own frame into N shares instead (total work fixed).  `config` says which.
+`python bench.py --gpus N` from a plain shell starts its own N ranks (torch.distributed.run, 127.0.0.1) before anything
+touches the GPU; under torch.distributed.run it is one of the ranks.  On a box with fewer GPUs than ranks the ranks
+share devices and gather through gloo (a rehearsal).
 """
 import argparse
 import csv
@@ -209,7 +211,8 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--aa", type=int, default=0, help="override the workload's antialiasing (spp = aa^2); recorded in config")
     ap.add_argument("--cam", default="", help="override the workload's frame, WxH; recorded in config")
-    ap.add_argument("--weak", action="store_true", help="N > 1: grow the frame with N (fixed work per GPU) instead of splitting one frame")
+    ap.add_argument("--weak", action="store_true", help="N > 1: grow the frame with N (fixed work per GPU); the default")
+    ap.add_argument("--strong", action="store_true", help="N > 1: split the workload's own frame over the ranks (fixed total work) instead of growing it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic and the VALU count stay null)")
     ap.add_argument("--small-sky", action="store_true", help="use a strided skybox (debug)")
@@ -264,9 +267,10 @@ def main():
     max_depth, shadow_rays = wl["max_depth"], wl["shadow_rays"]
     base_wh = tuple(int(v) for v in args.cam.split("x")) if args.cam else wl["cam"]
     cam_wh = base_wh
-    if world > 1 and args.weak:  # weak scaling: world x the pixels, same aspect ratio
-        w = int(round(base_wh[0] * (world ** 0.5) / 8.0)) * 8
-        cam_wh = (w, int(round(world * base_wh[0] * base_wh[1] / w)))
+    weak = world > 1 and not args.strong
+    if weak:  # world x the pixels, same camera and aspect ratio, whole tiles
+        k = world ** 0.5
+        cam_wh = (max(1, int(round(base_wh[0] * k / TILE))) * TILE, max(1, int(round(base_wh[1] * k / TILE))) * TILE)
     sky = rt.load_skybox(max_width=1024 if args.small_sky else None)
     t0 = time.perf_counter()
     scene = make_scene(rt.Scene, wl["scene"], sky, cam_wh, gpu_build=True)
@@ -427,12 +431,12 @@ def main():
         line = {
             "metric": "Mrays/s (primary + diffuse bounce) on bunny BVH", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if (world > 1 and args.weak) else "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "reference assets (bunny.ply, skybox.jpg) + generated instance / sphere placement" if wl["scene"][0] != "main"
                     else "reference assets (bunny.ply, skybox.jpg)",
             "config": {"workload": args.workload, "baseline_config": wl["baseline_config"], "width": W, "height": H, "spp": aa * aa, "max_depth": max_depth,
                        "shadow_rays": shadow_rays, "scatter_rays": 1, "tile": TILE,
-                       "parallelism": (f"tiles{world} of one {W}x{H} frame" if not args.weak else f"tiles{world}, frame grown from {base_wh[0]}x{base_wh[1]} per GPU") if world > 1 else "single",
+                       "parallelism": (f"tiles{world} of one {W}x{H} frame" if not weak else f"tiles{world} of a {W}x{H} frame: {base_wh[0]}x{base_wh[1]} pixels' worth per GPU") if world > 1 else "single",
                        "backend": ("rccl" if backend == "nccl" else backend + " (ranks share devices: rehearsal)") if world > 1 else None,
                        "reduced_from_workload": reduced, "scene": wl["desc"], "host_build_s": host_build_s, "upload_s": upload_s},
             "rays_per_step": {"closest": closest_per_step, "any": any_per_step, "paths": paths_per_step},
@@ -446,8 +450,8 @@ def main():
                                  "owned_tiles": [p["owned_tiles"] for p in per_rank], "rays_per_rank": [p["rays_per_step"] for p in per_rank],
                                  "note": "render = this rank's tiles through the wavefront kernels (blocking); gather = the framebuffer gather to rank 0 "
                                          "(a rank that finishes early waits here for the slowest); ms_per_step is the slowest rank's total"}
-        line["config"]["strong_scaling_workloads"] = ("spheres_10k_3840x2160_64spp_depth5 and bunny_grid_230x230_7680x4320_256spp_depth5 (BASELINE configs[3], [4]) are the "
-                                                      "frames meant for 2 / 4 / 8 GPUs: a pixel's samples are sequential (one random stream per pixel, integrator.rs:36), so a "
+        line["config"]["strong_scaling_workloads"] = ("with --strong: spheres_10k_3840x2160_64spp_depth5 and bunny_grid_230x230_7680x4320_256spp_depth5 (BASELINE configs[3], [4]) are the "
+                                                      "fixed frames meant for 2 / 4 / 8 GPUs: a pixel's samples are sequential (one random stream per pixel, integrator.rs:36), so a "
                                                       "frame is spp x max_depth dependent launch steps whatever the tile count, and the 1080x960 frame cut in eight runs "
                                                       "every step at its latency floor")
         line.update(extra)
