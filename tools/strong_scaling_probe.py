@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--ranks", default="1,2,4,8")
+    ap.add_argument("--tile", type=int, default=40)
     ap.add_argument("--opt", default="", help="tuning overrides, e.g. static=0,chunk=128,streams=2,max_paths=1048576")
     args = ap.parse_args()
     rt = entry.load_package()
@@ -37,7 +38,7 @@ def main():
         scene.set_option(opt_ids[k], int(v))
     base = None
     for n in [int(v) for v in args.ranks.split(',')]:
-        region = rt.Scene.make_region(w, h, tile=(64, 64), tile_first=0, tile_stride=n)
+        region = rt.Scene.make_region(w, h, tile=(args.tile, args.tile), tile_first=0, tile_stride=n)
         scene.render(max_depth=args.depth, shadow_rays=1, antialiasing=1, region=region)
         best = None
         for _ in range(args.reps):
