@@ -247,9 +247,12 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
     if ((rc = wave_alloc(ctx, ws, &W.rng_lo, cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.rng_hi, cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.sum, 3 * cap))) return rc;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 2; k++) {
         if ((rc = wave_alloc(ctx, ws, &W.Lb[k], 3 * cap))) return rc;
+        if ((rc = wave_alloc(ctx, ws, &W.Lpb[k], 3 * cap))) return rc;
+    }
     W.L = W.Lb[0];
+    W.Lp = W.Lpb[0];
     if ((rc = wave_alloc(ctx, ws, &W.beta, 3 * cap))) return rc;
     for (int k = 0; k < 2; k++) {
         if ((rc = wave_alloc(ctx, ws, &W.q_slot[k], cap))) return rc;
@@ -260,7 +263,7 @@ int ensure_wave(rtamd_context* ctx, rtamd_context::Workspace& ws, size_t cap, ui
     if ((rc = wave_alloc(ctx, ws, &W.p_ray, 6 * cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.p_rec, 2 * cap))) return rc;
     if ((rc = wave_alloc(ctx, ws, &W.p_pix, cap))) return rc;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 4; k++) {
         ShadeSet& T = W.set[k];
         if ((rc = wave_alloc(ctx, ws, &T.lit_slot, cap))) return rc;
         if ((rc = wave_alloc(ctx, ws, &T.lit_f, 6 * cap))) return rc;
@@ -1077,7 +1080,7 @@ int render_depth_first_rounds(rtamd_context* ctx, const rtamd_camera* cam, const
         for (uint32_t r = 0;; r++) {
             const uint32_t in = (r % 3u) * CS::TOTAL, nxt = ((r + 1u) % 3u) * CS::TOTAL, zero = ((r + 2u) % 3u) * CS::TOTAL;
             timed_begin(ctx, 0, st);
-            HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, r & 1u, in + CS::Q, MISS, in + CS::ANY, MISS, in + CS::HEAD, upper, st));
+            HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, r & 1u, in + CS::Q, MISS, in + CS::ANY, MISS, 0u, 1u, in + CS::HEAD, upper, st));
             timed_end(ctx, st);
             timed_begin(ctx, 2, st);
             HIP_TRY(ctx, launch_df_step(ctx->S, ctx->cfg, W, F, (uint32_t)begin, r & 1u, in, nxt, zero, chunk_n, st));
@@ -1285,6 +1288,8 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
     const CameraDev C = make_camera(*cam);
 
     static const bool host_timing = std::getenv("RTAMD_HOST_TIMING") != nullptr;
+    // the resolve of bounce d - 1 and the shading of bounce d as one launch (0: two launches, one after the other)
+    static const bool merge_resolve = !(std::getenv("RTAMD_MERGE_RESOLVE") && std::atoi(std::getenv("RTAMD_MERGE_RESOLVE")) == 0);
     const auto ht0 = std::chrono::steady_clock::now();
     hipEvent_t ev0 = get_event(ctx), ev1 = get_event(ctx);
     HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
@@ -1311,28 +1316,29 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                 const size_t any_upper = (size_t)chunk_n * (S_total ? S_total : 1);
                 const uint32_t n_pass = aa * aa;
                 const int sr = integ->shadow_rays;
-                // Sample pass k works in counter set k % 3 and radiance buffer k & 1.  Bounce 0 leaves its lit queue and
-                // shadow rays in shade set 1, the other bounces in set 0.  Two kinds of rays do not get a trace launch
-                // of their own: the shadow rays of a pass's last bounce ride with the first trace launch of the next
-                // pass (after the last pass: a launch of their own) and are resolved into buffer k & 1 while pass k + 1
-                // fills the other one; and, for max_depth >= 2, the primary rays of pass k + 1, which depend on nothing
-                // that pass k computes, ride with the last bounce of pass k.
+                // Sample pass k works in counter set k % 3 and radiance buffers k & 1; bounce d of pass k leaves its lit queue and
+                // shadow rays in shade set 2 * (k & 1) + (d & 1).  Two kinds of rays do not get a trace launch of their own: the
+                // shadow rays of a pass's last bounce ride with the first trace launch of the next pass (after the last pass: a
+                // launch of their own) and are resolved into the buffers k & 1 while pass k + 1 fills the other ones; and, for
+                // max_depth >= 2, the primary rays of pass k + 1, which depend on nothing that pass k computes, ride with the
+                // last bounce of pass k.  The lit hits of bounce d - 1 are resolved by the launch that shades bounce d.
                 const uint32_t cb = (pass % 3u) * CS::TOTAL, pb = ((pass + 2u) % 3u) * CS::TOTAL, nb = ((pass + 1u) % 3u) * CS::TOTAL;
-                WaveBufs Wp = W;                        // the previous pass's view: its radiance buffer
-                W.L = W.Lb[pass & 1u];
-                Wp.L = W.Lb[(pass + 1u) & 1u];
-                const uint32_t last_set = D - 1 > 0 ? 0u : 1u;   // shade set of a pass's last bounce
+                auto sset = [](uint32_t p, int d) -> uint32_t { return 2u * (p & 1u) + ((uint32_t)d & 1u); };
+                WaveBufs Wp = W;                        // the previous pass's view: its radiance buffers
+                W.L = W.Lb[pass & 1u]; W.Lp = W.Lpb[pass & 1u];
+                Wp.L = W.Lb[(pass + 1u) & 1u]; Wp.Lp = W.Lpb[(pass + 1u) & 1u];
+                // the lit hits of the previous pass's last bounce (the end of its samples: a skybox term may be pending)
+                const ResolveJob carried{Wp.L, Wp.Lp, pb + CS::LIT + (uint32_t)(D > 0 ? D - 1 : 0), sset(pass + 1u, D > 0 ? D - 1 : 0), 1u};
                 if (pass == n_pass) {
                     if (D > 0 && n_pass > 0) {  // shadow rays of the last bounce of the last pass
                         timed_begin(ctx, 1, st);
-                        HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, Wp, 0, MISS, MISS, last_set ? MISS : pb + CS::ANY + (D - 1),
-                                                       last_set ? pb + CS::ANY + (D - 1) : MISS, pb + CS::HEAD + D, any_upper, st));
+                        HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, Wp, 0, MISS, MISS, pb + CS::ANY + (D - 1), MISS, carried.set, 0u, pb + CS::HEAD + D, any_upper, st));
                         timed_end(ctx, st);
-                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, pb + CS::LIT + (D - 1), last_set, chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, carried, chunk_n, st));
                         launches += 2;
                     }
-                    // unfolded so far: pass n_pass - 2 (in the buffer this index would use) and pass n_pass - 1
-                    HIP_TRY(ctx, launch_finalize(W, R, (uint32_t)begin, chunk_n, (float)n_pass, n_pass >= 2 ? W.L : nullptr, Wp.L, out, st));
+                    // unfolded so far: pass n_pass - 2 (in the buffers this index would use) and pass n_pass - 1
+                    HIP_TRY(ctx, launch_finalize(W, R, (uint32_t)begin, chunk_n, (float)n_pass, n_pass >= 2 ? W.L : nullptr, W.Lp, Wp.L, Wp.Lp, out, st));
                     launches++;
                     continue;
                 }
@@ -1356,48 +1362,57 @@ int rtamd_render_device(rtamd_context* ctx, const rtamd_camera* cam, const rtamd
                     launches++;
                     if (D <= 0) {  // integrate_recur returns the skybox immediately (integrator.rs:59-61)
                         HIP_TRY(ctx, launch_mark_miss(W, cb + CS::PQ, chunk_n, st));
-                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, 1, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, none, chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, sset(pass, 0), 0, 1, sr, fold, cb + CS::PQ, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot,
+                                                       none, chunk_n, nullptr, nullptr, st));
                         launches += 2;
                         continue;
                     }
-                    // primary rays; with max_depth = 1 also the shadow rays of the previous pass (its only bounce: set 1)
+                    // primary rays; with max_depth = 1 also the shadow rays of the previous pass (its only bounce)
                     const bool carry = D == 1 && pass > 0;
                     timed_begin(ctx, 0, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, 0, MISS, pq, MISS, carry ? pb + CS::ANY + 0 : MISS, cb + CS::HEAD + 0,
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, 0, MISS, pq, MISS, carry ? pb + CS::ANY + 0 : MISS, 0u, carried.set, cb + CS::HEAD + 0,
                                                    chunk_n + (carry ? any_upper : 0), st));
                     timed_end(ctx, st);
                     launches++;
                     if (carry) {
-                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, pb + CS::LIT + 0, 1u, chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, carried, chunk_n, st));
                         launches++;
                     }
                 }
                 timed_begin(ctx, 2, st);
-                HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, 0, D, sr, fold, pq, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, next, chunk_n, st));
+                HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, sset(pass, 0), 0, D, sr, fold, pq, cb + CS::Q + 1, cb + CS::LIT + 0, cb + CS::ANY + 0, S_shoot, next, chunk_n,
+                                               nullptr, nullptr, st));
                 timed_end(ctx, st);
                 launches++;
                 for (int d = 1; d < D; d++) {
                     const bool ahead = d == D - 1 && pass + 1 < n_pass;   // the next pass's primary rays ride with this launch
                     // closest-hit rays of bounce d with the shadow rays of the bounce before; bounce 1 also takes the shadow
-                    // rays that the previous pass's last bounce left in set 0
+                    // rays that the previous pass's last bounce left
                     const bool carry = d == 1 && pass > 0;
-                    const uint32_t a0 = d == 1 ? (carry ? pb + CS::ANY + (D - 1) : MISS) : cb + CS::ANY + (d - 1);
-                    const uint32_t a1 = d == 1 ? cb + CS::ANY + 0 : MISS;
+                    const uint32_t a0 = carry ? pb + CS::ANY + (D - 1) : MISS;
+                    const uint32_t a1 = cb + CS::ANY + (d - 1);
                     timed_begin(ctx, 0, st);
-                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, (uint32_t)(d & 1), cb + CS::Q + d, ahead ? pq : MISS, a0, a1, cb + CS::HEAD + d,
-                                                   chunk_n + (ahead ? chunk_n : 0) + (a0 != MISS ? any_upper : 0) + (a1 != MISS ? any_upper : 0), st));
+                    HIP_TRY(ctx, launch_wave_trace(ctx->S, ctx->cfg, W, (uint32_t)(d & 1), cb + CS::Q + d, ahead ? pq : MISS, a0, a1, carried.set, sset(pass, d - 1),
+                                                   cb + CS::HEAD + d, chunk_n + (ahead ? chunk_n : 0) + (a0 != MISS ? any_upper : 0) + any_upper, st));
                     timed_end(ctx, st);
                     launches++;
                     timed_begin(ctx, 2, st);
-                    if (carry) {
-                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, pb + CS::LIT + (D - 1), 0u, chunk_n, st));
+                    const ResolveJob before{W.L, W.Lp, cb + CS::LIT + (uint32_t)(d - 1), sset(pass, d - 1), 0u};
+                    if (merge_resolve) {
+                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, sset(pass, d), d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, S_shoot,
+                                                       none, chunk_n, carry ? &carried : nullptr, &before, st));
                         launches++;
+                    } else {
+                        if (carry) {
+                            HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, Wp, sr, carried, chunk_n, st));
+                            launches++;
+                        }
+                        HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, sr, before, chunk_n, st));
+                        HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, sset(pass, d), d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, S_shoot,
+                                                       none, chunk_n, nullptr, nullptr, st));
+                        launches += 2;
                     }
-                    HIP_TRY(ctx, launch_wave_resolve(ctx->S, ctx->cfg, W, sr, cb + CS::LIT + (d - 1), d == 1 ? 1u : 0u, chunk_n, st));
-                    launches++;
-                    HIP_TRY(ctx, launch_wave_shade(ctx->S, ctx->cfg, W, d, D, sr, 0u, cb + CS::Q + d, cb + CS::Q + d + 1, cb + CS::LIT + d, cb + CS::ANY + d, S_shoot, none, chunk_n, st));
                     timed_end(ctx, st);
-                    launches++;
                 }
             }
         }

@@ -70,6 +70,12 @@ struct WaveBufs {
     float* L;             // 3*cap: radiance of the sample the launch works on (one of Lb, set by the host per launch)
     float* Lb[2];         // the two radiance buffers: sample pass k accumulates into Lb[k & 1] while the last shadow rays
                           // of pass k-1 are still being resolved into the other one
+    // 3*cap, one per radiance buffer: the skybox term that ends a sample's path (a ray that misses, or the scatter ray of the
+    // last bounce).  The shade launch leaves it here instead of adding it to L, so that it writes nothing the resolve launch
+    // of the bounce before it writes and the two can run side by side; it is added in the place the sum would have had it:
+    // by the resolve of the last bounce's lit hit, else when the sample is folded into the pixel sum.
+    float* Lp;
+    float* Lpb[2];
     float* beta;          // 3*cap: path throughput
     // closest-hit ray queues of the bounces d >= 1, double buffered by bounce parity
     uint32_t* q_slot[2];  // cap: pixel slot of the path
@@ -85,10 +91,11 @@ struct WaveBufs {
     // Rays of a wave finish in no particular order, so their results are scattered writes; as one
     // record they touch one cache line per ray instead of five.
     uint4* h_rec;         // 2*cap
-    // What a shade launch leaves for the trace and resolve launches after it.  Two sets: bounce 0 writes set 1,
-    // the other bounces set 0, because the last bounce of pass k and bounce 0 of pass k+1 are shaded back to
-    // back and their shadow rays are traced by the same launch.
-    ShadeSet set[2];
+    // What a shade launch leaves for the trace and resolve launches after it.  Four sets: bounce d of sample pass k writes
+    // set 2 * (k & 1) + (d & 1).  The shade launch of bounce d runs beside the resolve launch of bounce d - 1 (other bounce
+    // parity), and the lit hits of a pass's last bounce are resolved during the next pass (other pass parity).  (The
+    // depth-first rounds and the frame kernel use set 0 only.)
+    ShadeSet set[4];
     // counters: three sets of CounterSlots::TOTAL (sample pass k uses set k % 3, zeroed before its primary rays are
     // generated, i.e. during pass k-1, while the last counters of pass k-2 may still be in use); kernels take absolute
     // indices into this array
@@ -134,20 +141,28 @@ hipError_t launch_raygen(const WaveBufs& W, const RegionDev& R, const CameraDev&
                          uint32_t si, uint32_t sj, uint32_t aa, bool first, uint32_t p_idx, hipStream_t st);
 hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hipStream_t st);
 // One launch over up to four queues (counter index MISS: absent): bounce rays q_ray[cur], primary rays, shadow rays of
-// set 0 and of set 1.
+// shade set a0_set (length counter a0_idx) and of shade set a1_set (a1_idx).
 hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t p_idx,
-                             uint32_t a0_idx, uint32_t a1_idx, uint32_t head_idx, size_t upper, hipStream_t st);
-// depth 0 shades the primary queue into set 1 and starts the sample: fold = 2 adds the old content of W.L (the sample
-// two passes back) to the pixel sum first, then W.L and the throughput are reset; other depths use set 0.
+                             uint32_t a0_idx, uint32_t a1_idx, uint32_t a0_set, uint32_t a1_set, uint32_t head_idx, size_t upper, hipStream_t st);
+// A resolve job: the lit queue of shade set `set` (length counter lit_idx; MISS: no job) is resolved into the radiance
+// buffer L; last != 0: the lit hits of a pass's last bounce, whose pixel may hold a pending skybox term in Lp (WaveBufs::Lp).
+struct ResolveJob {
+    float* L;
+    float* Lp;
+    uint32_t lit_idx, set, last;
+};
+// depth 0 shades the primary queue and starts the sample: fold = 2 adds the old content of W.L and W.Lp (the sample
+// two passes back) to the pixel sum first, then W.L, W.Lp and the throughput are reset.  `set`: the shade set it fills.
 // n_shoot: shadow rays per lit hit = light samples of the lights that can need one (not ambient, not reach 0).
-hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
+// r0, r1: resolve jobs that run beside it in the same launch, on blocks of their own (null: none); they must not read the
+// set the shade part fills.
+hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t set, int depth, int max_depth, int shadow_rays, uint32_t fold,
                              uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, const NextPass& next, size_t upper,
-                             hipStream_t st);
-hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set,
-                               size_t upper, hipStream_t st);
-// pixel = (sum + L_first + L_second) / n_samples; L_first may be null (a single sample pass)
+                             const ResolveJob* r0, const ResolveJob* r1, hipStream_t st);
+hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, const ResolveJob& job, size_t upper, hipStream_t st);
+// pixel = (sum + (L_first + Lp_first) + (L_second + Lp_second)) / n_samples; L_first may be null (a single sample pass)
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L_first,
-                           const float* L_second, float* out, hipStream_t st);
+                           const float* Lp_first, const float* L_second, const float* Lp_second, float* out, hipStream_t st);
 // The whole integrator, depth first, one lane per pixel slot (any scatter_rays).  stack: max_depth * 20 * cap floats;
 // out: the chunk's pixels (3 floats per slot, written for every slot); stats[0..1] += closest-hit / any-hit rays.
 hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, const RegionDev& R, const CameraDev& cam, int max_depth, int shadow_rays,

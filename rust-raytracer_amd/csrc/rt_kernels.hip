@@ -269,8 +269,8 @@ struct WaveIO {
     uint4* p_rec;
     uint8_t *vis0, *vis1;
     uint32_t cap, any_cap;
-    // Items [0, n_q) are bounce rays, [n_q, n_closest) primary rays, [n_closest, n_a0) shadow rays of set 0, the rest
-    // shadow rays of set 1 (words 6 and 7 of a closest-hit ray are ignored and point at its first word).
+    // Items [0, n_q) are bounce rays, [n_q, n_closest) primary rays, [n_closest, n_a0) shadow rays of the first shade set, the rest
+    // shadow rays of the second (words 6 and 7 of a closest-hit ray are ignored and point at its first word).
     uint32_t n_q, n_closest, n_a0;
     __device__ __forceinline__ void stage_addr(uint32_t i, const void* (&src)[8]) const {
         const bool a = i >= n_closest;
@@ -306,7 +306,7 @@ struct WaveIO {
 };
 
 template <int MESHLOC, int TABKIND, bool LEAN>
-__global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
+__global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PER_SIMD : SCHED_WAVES_PER_SIMD) void k_wave_trace(DevScene S, WaveBufs W, ShadeSet A0, ShadeSet A1, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
                                                             uint32_t a1_idx, uint32_t head_idx, uint32_t chunk_hint) {
     // queue lengths written by the previous stages (index MISS: that queue is absent)
     const uint32_t n_q = q_idx == MISS ? 0u : W.counts[q_idx];
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
     LdsTab ltab;
     MidTab mtab;
     stage_scene<MESHLOC, TABKIND>(S, lds, ltab, mtab);
-    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.p_ray, W.set[0].a_ray, W.set[1].a_ray, W.set[0].a_vidx, W.set[1].a_vidx, W.h_rec, W.p_rec,
-              W.set[0].vis, W.set[1].vis, W.cap, W.any_cap, n_q, n_closest, n_closest + n_a0};
+    WaveIO io{cur ? W.q_ray[1] : W.q_ray[0], W.p_ray, A0.a_ray, A1.a_ray, A0.a_vidx, A1.a_vidx, W.h_rec, W.p_rec,
+              A0.vis, A1.vis, W.cap, W.any_cap, n_q, n_closest, n_closest + n_a0};
     if (TABKIND == TAB_LDS) trace_scheduler<MESHLOC, LEAN>(S, ltab, lds, io, &W.counts[head_idx], n, chunk, stage, coop, ostack);
     else if (TABKIND == TAB_MID) trace_scheduler<MESHLOC, LEAN>(S, mtab, lds, io, &W.counts[head_idx], n, chunk, stage, coop, ostack);
     else trace_scheduler<MESHLOC, LEAN>(S, GlobalTab{&S}, lds, io, &W.counts[head_idx], n, chunk, stage, coop, ostack);
@@ -351,13 +351,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, MESHLOC == MESH_NONE ? NOMESH_WAVES_PE
 // `T` is the shade set the launch fills.  Bounce 0 (`fold` != 0) reads the primary queue and starts the pixel's next
 // sample: fold 2 adds the radiance buffer's old content (the sample two passes back, complete by now) to the
 // pixel sum in generation order (integrator.rs:50-53), fold 1 and 2 zero the buffer; the throughput starts at 1.
-__global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
-                                                    uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot,
-                                                    NextPass next) {
+// (block `bid` of `n_blocks` blocks of the launch that shade)
+__device__ __forceinline__ void shade_part(const DevScene& S, const WaveBufs& W, const ShadeSet& T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
+                                           uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot,
+                                           const NextPass& next, const uint32_t bid, const uint32_t n_blocks) {
     __shared__ uint32_t sh_app[STAGE_BLOCK / 64 + 2];
     SHADE_PROBE_DECL
     const uint32_t n = W.counts[q_in_idx];
-    if (next.zero_base != MISS && blockIdx.x == 0)   // nothing reads or appends to that set before this launch is over
+    if (next.zero_base != MISS && bid == 0)   // nothing reads or appends to that set before this launch is over
         for (uint32_t k = threadIdx.x; k < CounterSlots::TOTAL; k += blockDim.x) W.counts[next.zero_base + k] = 0u;
     const bool odd = (depth & 1) != 0;
     const float* r = fold ? W.p_ray : (odd ? W.q_ray[1] : W.q_ray[0]);
@@ -367,11 +368,11 @@ __global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shad
     uint32_t* q_slot_out = odd ? W.q_slot[0] : W.q_slot[1];
     const uint32_t cap = W.cap;
     const size_t ac = W.any_cap;
-    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t stride = n_blocks * blockDim.x;
     const uint32_t n_iter = (n + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; it++) {
         // ---- phase A: load the path, classify (miss / lit / unlit) ----
-        uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t i = it * stride + bid * blockDim.x + threadIdx.x;
         bool active = i < n;
         bool hit = false, lit = false, cont = false;
         uint32_t slot = 0, mat = MISS;
@@ -387,12 +388,13 @@ __global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shad
                 W.p_ray[i + 3 * cap] = nd.x; W.p_ray[i + 4 * cap] = nd.y; W.p_ray[i + 5 * cap] = nd.z;
             }
             if (fold) {
-                if (fold == 2u) {
-                    W.sum[slot] = W.sum[slot] + W.L[slot];
-                    W.sum[slot + cap] = W.sum[slot + cap] + W.L[slot + cap];
-                    W.sum[slot + 2 * cap] = W.sum[slot + 2 * cap] + W.L[slot + 2 * cap];
+                if (fold == 2u) {   // (the pending skybox term is the sample's last)
+                    W.sum[slot] = W.sum[slot] + (W.L[slot] + W.Lp[slot]);
+                    W.sum[slot + cap] = W.sum[slot + cap] + (W.L[slot + cap] + W.Lp[slot + cap]);
+                    W.sum[slot + 2 * cap] = W.sum[slot + 2 * cap] + (W.L[slot + 2 * cap] + W.Lp[slot + 2 * cap]);
                 }
                 W.L[slot] = 0.0f; W.L[slot + cap] = 0.0f; W.L[slot + 2 * cap] = 0.0f;
+                W.Lp[slot] = 0.0f; W.Lp[slot + cap] = 0.0f; W.Lp[slot + 2 * cap] = 0.0f;
             } else {
                 beta = mk(W.beta[slot], W.beta[slot + cap], W.beta[slot + 2 * cap]);
             }
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shad
             b.obj = rec0.x;
             if (b.obj == MISS) {  // integrator.rs:66
                 f3 c = beta * sky_color(S, dir);
-                W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
+                W.Lp[slot] = c.x; W.Lp[slot + cap] = c.y; W.Lp[slot + 2 * cap] = c.z;   // the path ends: its last term
             } else {
                 hit = true;
                 b.prim = rec0.y;
@@ -476,7 +478,8 @@ __global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shad
                 f3 nb = beta * w;
                 if (depth + 1 >= max_depth) {                          // integrator.rs:59-61 at depth+1
                     f3 c = nb * sky_color(S, out);
-                    W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
+                    // (it comes before this hit's own light in the sum: the resolve of this bounce adds it first)
+                    W.Lp[slot] = c.x; W.Lp[slot + cap] = c.y; W.Lp[slot + 2 * cap] = c.z;
                 } else {
                     cont = true;
                     next_pos = p2; next_dir = out;
@@ -509,10 +512,10 @@ __global__ void k_mark_miss(WaveBufs W, uint32_t q_idx) {
 // src/integrator.rs:107-132) and add `diffuse * illumination` (integrator.rs:87), weighted by the
 // path throughput, to the sample's radiance.  Sums run in the reference's order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, ShadeSet T, int32_t shadow_rays, uint32_t lit_idx) {
-    const uint32_t n = W.counts[lit_idx];
-    const uint32_t cap = W.cap;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+// (block `bid` of the `n_blocks` blocks that work on this lit queue; last: see ResolveJob)
+__device__ __forceinline__ void resolve_part(const DevScene& S, const uint32_t cap, float* L, float* Lp, const ShadeSet& T, int32_t shadow_rays, const uint32_t n,
+                                             const uint32_t bid, const uint32_t n_blocks, const uint32_t last) {
+    for (uint32_t j = bid * blockDim.x + threadIdx.x; j < n; j += n_blocks * blockDim.x) {
         const float* f = T.lit_f;
         f3 beta = mk(f[j], f[j + cap], f[j + 2 * cap]);
         f3 diffuse = mk(f[j + 3 * cap], f[j + 4 * cap], f[j + 5 * cap]);
@@ -538,15 +541,52 @@ __global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, Sh
         }
         f3 c = beta * (diffuse * illum);
         uint32_t slot = T.lit_slot[j];
-        W.L[slot] += c.x; W.L[slot + cap] += c.y; W.L[slot + 2 * cap] += c.z;
+        if (last) {   // the scatter ray of the last bounce left the skybox term of the sample's end: it precedes this hit's light
+            const f3 l0 = mk(L[slot] + Lp[slot], L[slot + cap] + Lp[slot + cap], L[slot + 2 * cap] + Lp[slot + 2 * cap]);
+            Lp[slot] = 0.0f; Lp[slot + cap] = 0.0f; Lp[slot + 2 * cap] = 0.0f;
+            L[slot] = l0.x + c.x; L[slot + cap] = l0.y + c.y; L[slot + 2 * cap] = l0.z + c.z;
+        } else {
+            L[slot] += c.x; L[slot + cap] += c.y; L[slot + 2 * cap] += c.z;
+        }
     }
+}
+__global__ __launch_bounds__(256) void k_wave_resolve(DevScene S, WaveBufs W, ShadeSet T, float* L, float* Lp, int32_t shadow_rays, uint32_t lit_idx, uint32_t last) {
+    resolve_part(S, W.cap, L, Lp, T, shadow_rays, W.counts[lit_idx], blockIdx.x, gridDim.x, last);
+}
+
+__global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shade(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
+                                                    uint32_t fold, uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot,
+                                                    NextPass next) {
+    shade_part(S, W, T, depth, max_depth, shadow_rays, fold, q_in_idx, q_out_idx, lit_idx, any_idx, n_shoot, next, blockIdx.x, gridDim.x);
+}
+// The shade launch of a bounce and, on blocks of their own behind the shading ones, up to two resolve jobs (the lit hits of the
+// bounce before it; with bounce 1 also those of the previous pass's last bounce).  The jobs write radiance buffers and read
+// shade sets that the shading blocks do not touch (WaveBufs::Lp, WaveBufs::set), so the parts need no order among them.
+struct ResolveJobDev {
+    float* L;
+    float* Lp;
+    ShadeSet T;
+    uint32_t lit_idx, last;
+};
+__global__ __launch_bounds__(STAGE_BLOCK, SHADE_WAVES_PER_SIMD) void k_wave_shade_resolve(DevScene S, WaveBufs W, ShadeSet T, int32_t depth, int32_t max_depth, int32_t shadow_rays,
+                                                            uint32_t q_in_idx, uint32_t q_out_idx, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot,
+                                                            uint32_t shade_blocks, uint32_t job_blocks, ResolveJobDev j0, ResolveJobDev j1) {
+    if (blockIdx.x < shade_blocks) {
+        NextPass none;
+        none.enabled = 0u; none.si = 0u; none.sj = 0u; none.aa = 0u; none.zero_base = MISS;
+        shade_part(S, W, T, depth, max_depth, shadow_rays, 0u, q_in_idx, q_out_idx, lit_idx, any_idx, n_shoot, none, blockIdx.x, shade_blocks);
+        return;
+    }
+    const uint32_t b = blockIdx.x - shade_blocks;
+    if (b < job_blocks) resolve_part(S, W.cap, j0.L, j0.Lp, j0.T, shadow_rays, W.counts[j0.lit_idx], b, job_blocks, j0.last);
+    else if (j1.lit_idx != MISS) resolve_part(S, W.cap, j1.L, j1.Lp, j1.T, shadow_rays, W.counts[j1.lit_idx], b - job_blocks, job_blocks, j1.last);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Stage 5: pixel = mean of the samples (integrator.rs:50-53), written to the tile-major output.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(WaveBufs W, RegionDev R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L1,
-                                                  const float* L2, float* out) {
+                                                  const float* Lp1, const float* L2, const float* Lp2, float* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= chunk_n) return;
     uint32_t cx, cy;
@@ -557,8 +597,8 @@ __global__ __launch_bounds__(256) void k_finalize(WaveBufs W, RegionDev R, uint3
 #pragma unroll
         for (uint32_t c = 0; c < 3; c++) {
             float v = W.sum[i + c * W.cap];
-            if (L1 != nullptr) v = v + L1[i + c * W.cap];
-            v = v + L2[i + c * W.cap];
+            if (L1 != nullptr) v = v + (L1[i + c * W.cap] + Lp1[i + c * W.cap]);
+            v = v + (L2[i + c * W.cap] + Lp2[i + c * W.cap]);
             out[o + c] = v / n_samples;
         }
     } else {
@@ -1066,37 +1106,46 @@ hipError_t launch_mark_miss(const WaveBufs& W, uint32_t q_idx, size_t upper, hip
     return hipGetLastError();
 }
 hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t cur, uint32_t q_idx, uint32_t p_idx, uint32_t a0_idx,
-                             uint32_t a1_idx, uint32_t head_idx, size_t upper, hipStream_t st) {
+                             uint32_t a1_idx, uint32_t a0_set, uint32_t a1_set, uint32_t head_idx, size_t upper, hipStream_t st) {
     uint32_t g = sched_grid(cfg, upper, S.n_meshes == 0);
-    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, cur, q_idx, p_idx, a0_idx, a1_idx, head_idx,
+    RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, W.set[a0_set & 3u], W.set[a1_set & 3u], cur, q_idx, p_idx, a0_idx, a1_idx, head_idx,
                            (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20));
     return hipGetLastError();
 }
-hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int depth, int max_depth, int shadow_rays, uint32_t fold,
+hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t set, int depth, int max_depth, int shadow_rays, uint32_t fold,
                              uint32_t q_in, uint32_t q_out, uint32_t lit_idx, uint32_t any_idx, uint32_t n_shoot, const NextPass& next, size_t upper,
-                             hipStream_t st) {
+                             const ResolveJob* r0, const ResolveJob* r1, hipStream_t st) {
     size_t need = (upper + STAGE_BLOCK - 1) / STAGE_BLOCK;
     size_t capg = (size_t)cfg.num_cus * (2048 / STAGE_BLOCK);
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
-    // bounce 0 fills shade set 1, the other bounces set 0
-    hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, W.set[fold ? 1 : 0], depth, max_depth, shadow_rays, fold, q_in, q_out,
-                       lit_idx, any_idx, n_shoot, next);
+    if (r0 == nullptr && r1 != nullptr) { r0 = r1; r1 = nullptr; }
+    if (r0 == nullptr) {
+        hipLaunchKernelGGL(k_wave_shade, dim3(g), dim3(STAGE_BLOCK), 0, st, S, W, W.set[set & 3u], depth, max_depth, shadow_rays, fold, q_in, q_out, lit_idx, any_idx,
+                           n_shoot, next);
+        return hipGetLastError();
+    }
+    // (the shade part of such a launch is never bounce 0: nothing to fold, no next pass to prepare)
+    size_t capj = (size_t)cfg.num_cus * 2;
+    const uint32_t jb = (uint32_t)(need < capj ? need : capj);
+    const ResolveJobDev j0{r0->L, r0->Lp, W.set[r0->set & 3u], r0->lit_idx, r0->last};
+    const ResolveJobDev j1 = r1 ? ResolveJobDev{r1->L, r1->Lp, W.set[r1->set & 3u], r1->lit_idx, r1->last} : ResolveJobDev{nullptr, nullptr, W.set[0], MISS, 0u};
+    hipLaunchKernelGGL(k_wave_shade_resolve, dim3(g + jb * (r1 ? 2u : 1u)), dim3(STAGE_BLOCK), 0, st, S, W, W.set[set & 3u], depth, max_depth, shadow_rays, q_in, q_out,
+                       lit_idx, any_idx, n_shoot, g, jb, j0, j1);
     return hipGetLastError();
 }
-hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, uint32_t lit_idx, uint32_t set, size_t upper,
-                               hipStream_t st) {
+hipError_t launch_wave_resolve(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, int shadow_rays, const ResolveJob& job, size_t upper, hipStream_t st) {
     size_t need = (upper + 255) / 256;
     size_t capg = (size_t)cfg.num_cus * 8;
     uint32_t g = (uint32_t)(need < capg ? need : capg);
     if (!g) g = 1;
-    hipLaunchKernelGGL(k_wave_resolve, dim3(g), dim3(256), 0, st, S, W, W.set[set ? 1 : 0], shadow_rays, lit_idx);
+    hipLaunchKernelGGL(k_wave_resolve, dim3(g), dim3(256), 0, st, S, W, W.set[job.set & 3u], job.L, job.Lp, shadow_rays, job.lit_idx, job.last);
     return hipGetLastError();
 }
 hipError_t launch_finalize(const WaveBufs& W, const RegionDev& R, uint32_t chunk_begin, uint32_t chunk_n, float n_samples, const float* L_first,
-                           const float* L_second, float* out, hipStream_t st) {
+                           const float* Lp_first, const float* L_second, const float* Lp_second, float* out, hipStream_t st) {
     uint32_t g = (chunk_n + 255) / 256;
-    hipLaunchKernelGGL(k_finalize, dim3(g), dim3(256), 0, st, W, R, chunk_begin, chunk_n, n_samples, L_first, L_second, out);
+    hipLaunchKernelGGL(k_finalize, dim3(g), dim3(256), 0, st, W, R, chunk_begin, chunk_n, n_samples, L_first, Lp_first, L_second, Lp_second, out);
     return hipGetLastError();
 }
 hipError_t launch_pixel_depth_first(const DevScene& S, const LaunchCfg& cfg, const RegionDev& R, const CameraDev& cam, int max_depth, int shadow_rays,
