@@ -369,6 +369,7 @@ int rtamd_create(int device_id, rtamd_context** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->cfg.num_cus = prop.multiProcessorCount;
+    if (const char* e = std::getenv("RTAMD_THIN_TAIL")) ctx->cfg.thin_tail = std::atoi(e) != 0 ? 1 : 0;   // (A/B of the scheduler's deal of mid-size queues)
     if (hipMalloc((void**)&ctx->work_head, HEAD_RING * sizeof(uint32_t)) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;

@@ -131,6 +131,7 @@ struct LaunchCfg {
     int min_batch = 4;             // rays per wave below which a short queue is not spread any thinner (1..64)
     int use_lds = 1;
     int scheduler = 1;             // 1: persistent phase-voting scheduler, 0: plain nested-loop kernels (batch entry points only)
+    int thin_tail = 1;             // 1: a queue of one to two batches per wave is dealt whole (a second, shorter batch per wave) instead of leaving its second part to the shared head
     int lean = 1;                  // 1: scenes of meshes + cuboids (or spheres + cuboids) under inline wrappers run the lean kernel form
 };
 

@@ -1055,7 +1055,7 @@ static inline uint32_t sched_chunk(const LaunchCfg& cfg, size_t n, uint32_t grid
     uint32_t chunk = (uint32_t)cfg.chunk;
     const size_t waves = (size_t)grid * (TRACE_BLOCK / 64);
     while (chunk > 64 && (n / chunk) < waves * 4) chunk >>= 1;
-    return chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20);
+    return chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20) | ((uint32_t)(cfg.thin_tail != 0) << 28);
 }
 
 hipError_t launch_trace_closest(const DevScene& S, const LaunchCfg& cfg, const RayBatch& rays, const HitBatch& out, size_t n, uint32_t* work_head, hipStream_t st) {
@@ -1109,7 +1109,7 @@ hipError_t launch_wave_trace(const DevScene& S, const LaunchCfg& cfg, const Wave
                              uint32_t a1_idx, uint32_t a0_set, uint32_t a1_set, uint32_t head_idx, size_t upper, hipStream_t st) {
     uint32_t g = sched_grid(cfg, upper, S.n_meshes == 0);
     RTAMD_DISPATCH_MESHLOC(S, cfg, k_wave_trace, g, st, S, W, W.set[a0_set & 3u], W.set[a1_set & 3u], cur, q_idx, p_idx, a0_idx, a1_idx, head_idx,
-                           (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20));
+                           (uint32_t)cfg.chunk | ((uint32_t)cfg.static_share << 16) | ((uint32_t)cfg.min_batch << 20) | ((uint32_t)(cfg.thin_tail != 0) << 28));
     return hipGetLastError();
 }
 hipError_t launch_wave_shade(const DevScene& S, const LaunchCfg& cfg, const WaveBufs& W, uint32_t set, int depth, int max_depth, int shadow_rays, uint32_t fold,
