@@ -659,7 +659,6 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     const uint32_t n_batches = (n_items + bs - 1u) / bs;
     uint32_t k_static = n_batches <= n_waves ? 1u : (share8 * n_batches) / (8u * n_waves);
     if (k_static == 0u) k_static = 1u;
-    const uint64_t dyn_base64 = (uint64_t)k_static * n_waves * bs;
     // A queue of between one and two batches per wave: what the first batches leave is dealt too, as one shorter batch per
     // wave.  Left to the shared head it would go to the waves whose claims arrive first -- every wave asks as soon as its
     // first batch is handed out -- and those would hold twice the rays of the others, a launch of two batch times
@@ -668,7 +667,9 @@ __device__ __forceinline__ void trace_scheduler(const DevScene& S, const Tab& ta
     if ((chunk_and_share >> 28) & 1u) {
         const uint64_t full = (uint64_t)n_waves * 64u;
         if (k_static == 1u && n_items > full && n_items <= 2u * full) tail_bs = (uint32_t)((n_items - full + n_waves - 1u) / n_waves);
+        else if (k_static == 1u && n_items > 2u * full) k_static = 2u;   // (the same rush for the shared head otherwise; by the second batch the waves are apart)
     }
+    const uint64_t dyn_base64 = (uint64_t)k_static * n_waves * bs;
     const uint32_t k_rounds = k_static + (tail_bs != 0u ? 1u : 0u);
     const uint32_t dyn_base = (tail_bs == 0u && dyn_base64 < n_items) ? (uint32_t)dyn_base64 : n_items;
     uint32_t ks = 0;

@@ -18,7 +18,7 @@ from test_gpu_trace import random_rays  # noqa: E402
 rt = entry.load_package()
 gpu = rt.Scene.main(sky=rt.load_skybox(max_width=512), cam=(1080, 960)).upload(0)
 gpu.set_option(rt.OPT_PROFILE, 1)
-for n in (64, 1024, 16384, 65536, 131072, 262144, 524288, 1048576, 2097152):
+for n in (64, 16384, 131072, 262144, 393216, 524288, 600000, 700000, 786432, 1048576, 2097152):
     rays = random_rays(n, seed=5, center=(0, 0, 1), radius=6.0)
     best = 1e9
     for _ in range(5):
